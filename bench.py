@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""bench.py -- node-embeddings/sec of the GraphSAGE 2-hop mean-aggregate forward on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one 2-hop forward (sample both hops + frontier dedupe + layer 1 on the frontier +
+layer 2 on the seeds) over one batch of B seed nodes, through the C ABI (sage_forward2).
+Workload at every N: BASELINE.json configs[2] -- synthetic R-MAT 2^20 nodes / 16 M edges,
+256-dim fp32 features, fanout 15/25, H = 128/128, B = 4096 seeds per GPU -- the configuration the
+roofline target is quoted on.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
+graph, table and weights are replicated, every rank draws its own seed batches (seed-node shard,
+weak scaling), and the forward needs no collective; barrier + max-over-ranks timing only.
+
+Inputs are resident in HBM before the timed region; outputs stay on the device.  Rank 0 prints
+ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "graphsage-simple_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+CACHE_DIR = os.environ.get("SAGE_CACHE", "/tmp/sage_cache")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SAGE_STREAMS", "4")),
+                    help="mini-batches in flight (each on its own HIP stream with its own workspace)")
+    ap.add_argument("--mode", choices=["gcn", "concat"], default="gcn",
+                    help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")
+    ap.add_argument("--unfused", action="store_true", help="two-launch layers (gather_mean + linear_act)")
+    ap.add_argument("--scale", type=int, default=20)
+    ap.add_argument("--edges", type=int, default=16_000_000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--k1", type=int, default=15)
+    ap.add_argument("--k2", type=int, default=25)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+class HipEvents:
+    """hipEvent_t pairs recorded by sage_forward2_profiled on the kernel's own stream."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+
+    def create(self):
+        ev = ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(ev)) == 0
+        return ev
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b)
+        assert rc == 0, rc
+        return ms.value
+
+    def destroy(self, ev):
+        self.hip.hipEventDestroy(ev)
+
+
+def algorithmic_bytes(d0, h1, h2, k1dim, k2dim, b, n_s1, e1, e2, n_r1):
+    """SURVEY.md 8(d) / BASELINE.md section 4: compulsory traffic of one forward, and the share of
+    its dominant kernel (layer 1: raw rows in, ids in, h1 out, W1)."""
+    layer1 = 4 * d0 * n_r1 + 4 * h1 * n_s1 + 4 * e1 + 4 * n_s1 + 4 * h1 * k1dim
+    total = (4 * d0 * n_r1 + 2 * 4 * h1 * n_s1 + 4 * h2 * b + 4 * (e1 + e2) + 16 * (n_s1 + b)
+             + 4 * (h1 * k1dim + h2 * k2dim))
+    return total, layer1
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL; only barriers + one MAX all-reduce of the time
+
+    from sage355 import native, ops
+    from sage355.engine import TwoHopEngine
+    from sage355.graph import rmat_graph
+    native.lib()
+
+    # ---- synthetic inputs: rank 0 generates, the others load its cache ----
+    if rank == 0:
+        graph = rmat_graph(args.scale, args.edges, seed=0, cache_dir=CACHE_DIR)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        graph = rmat_graph(args.scale, args.edges, seed=0, cache_dir=CACHE_DIR)
+    n = graph.num_nodes
+    concat = args.mode == "concat"
+    mult = 2 if concat else 1
+    d0, h1, h2, k1, k2, b = args.dim, args.hidden, args.hidden, args.k1, args.k2, args.batch
+    gen = torch.Generator(device=dev).manual_seed(0)
+    table = torch.randn(n, d0, generator=gen, device=dev)
+    wgen = torch.Generator().manual_seed(0)
+    w1 = ((torch.rand(h1, mult * d0, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h1 + mult * d0))).to(dev)
+    w2 = ((torch.rand(h2, mult * h1, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h2 + mult * h1))).to(dev)
+    rowptr, col = graph.to(dev)
+    deg = graph.degrees()
+    candidates = np.nonzero(deg > 0)[0]
+    total_steps = args.warmup + args.steps
+    rs = np.random.default_rng(1 + 7919 * rank)
+    seeds_host = np.stack([rs.choice(candidates, b, replace=False) for _ in range(total_steps)]).astype(np.int32)
+    seeds_dev = torch.from_numpy(seeds_host).to(dev)
+    sampler_seed = [0x5A6E355 + 1000003 * rank + i for i in range(total_steps)]
+
+    nstreams = max(1, args.streams)
+    engines = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, fused=not args.unfused, max_batch=b)
+               for _ in range(nstreams)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    outs = [torch.empty(b, h2, device=dev) for _ in range(nstreams)]
+
+    # ---- parity gate: one batch against the fp64 oracle on the GPU's own sampled sets ----
+    parity_err = None
+    if not args.no_parity and rank == 0:
+        from oracle import ref_sparse
+        o = engines[0].forward(seeds_dev[0], seed=sampler_seed[0]).cpu()
+        it = engines[0].intermediates()
+        first = it["first_frontier_row"]
+        s1, nbr1, cnt1 = it["s1_nodes"].cpu().numpy(), it["nbr1"].cpu().numpy(), it["cnt1"].cpu().numpy()
+        ref = ref_sparse.two_hop_forward(table.cpu(), w1.cpu(), w2.cpu(), seeds_host[0], it["nbr2"].cpu().numpy(),
+                                         it["cnt2"].cpu().numpy(), s1[first:], nbr1[first:], cnt1[first:], gcn=not concat,
+                                         seed_nbr1=nbr1[:first] if concat else None, seed_cnt1=cnt1[:first] if concat else None)
+        scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-30)
+        parity_err = ((o.double() - ref).abs() / scale).max().item()
+        if not parity_err <= 1e-5:
+            raise SystemExit(f"parity gate failed: max |gpu-oracle|/rowmax = {parity_err:.3e}")
+
+    def run(step_range, profiled_events=None):
+        for i in step_range:
+            s = i % nstreams
+            with torch.cuda.stream(streams[s]):
+                if profiled_events is None:
+                    engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s])
+                else:
+                    engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s], stage_events=profiled_events[i])
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, then the timed region: exactly K steps between two barrier+synchronize fences ----
+    run(range(args.warmup))
+    fence()
+    t0 = time.perf_counter()
+    run(range(args.warmup, total_steps))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * b * args.steps / elapsed
+
+    # ---- dominant kernel (layer 1) duration: same K steps again, HIP events on the kernel's own stream ----
+    layer1_ms = layer_ms = None
+    if rank == 0:
+        he = HipEvents()
+        evs = {}
+        for i in range(args.warmup, total_steps):
+            arr = (ctypes.c_void_p * 8)()
+            for j in range(8):
+                arr[j] = he.create()
+            evs[i] = arr
+        fence() if dist is None else torch.cuda.synchronize()
+        run(range(args.warmup, total_steps), evs)
+        torch.cuda.synchronize()
+        stage = np.zeros(4)
+        for i, arr in evs.items():
+            for sidx in range(4):
+                stage[sidx] += he.elapsed_ms(arr[2 * sidx], arr[2 * sidx + 1])
+            for j in range(8):
+                he.destroy(arr[j])
+        stage /= args.steps
+        layer1_ms = float(stage[2])
+        layer_ms = [float(x) for x in stage]
+
+    # ---- count the data-determined set sizes of every timed batch (untimed replay, same sets) ----
+    roofline = None
+    if rank == 0:
+        tot = l1 = 0.0
+        sizes = np.zeros(5)
+        for i in range(args.warmup, total_steps):
+            engines[0].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[0])
+            it = engines[0].intermediates()
+            cnt1, cnt2 = it["cnt1"], it["cnt2"]
+            kk = torch.arange(k1, device=dev)[None, :] < cnt1[:, None]
+            raw = it["nbr1"][kk]
+            if concat:
+                raw = torch.cat([raw, it["s1_nodes"]])
+            n_r1 = int(torch.unique(raw).numel())
+            e1, e2, n_s1 = int(cnt1.sum()), int(cnt2.sum()), it["n_s1"]
+            t_, l_ = algorithmic_bytes(d0, h1, h2, mult * d0, mult * h1, b, n_s1, e1, e2, n_r1)
+            tot += t_
+            l1 += l_
+            sizes += np.array([e2, n_s1, e1, n_r1, 4 * d0 * e1 + 4 * h1 * e2])
+        tot /= args.steps
+        l1 /= args.steps
+        sizes /= args.steps
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("layer1_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = l1 / (layer1_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "layer 1 (gather-mean + W1 contraction)" + ("" if not args.unfused else " [gather_mean]"),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
+            "traffic": traffic, "bytes_per_launch": round(l1), "kernel_ms": round(layer1_ms, 5),
+            "stage_ms": {"sample_outer": round(layer_ms[0], 5), "sample_inner": round(layer_ms[1], 5),
+                         "layer1": round(layer_ms[2], 5), "layer2": round(layer_ms[3], 5)},
+            "forward_bytes": round(tot), "forward_GBps": round(tot / (ms_per_step * 1e-3) / 1e9, 1),
+            "forward_frac": round(tot / (ms_per_step * 1e-3) / HBM_PEAK, 4),
+            "per_edge_gather_bytes": round(float(sizes[4])),
+            "mean_sizes": {"E2": round(float(sizes[0]), 1), "S1": round(float(sizes[1]), 1), "E1": round(float(sizes[2]), 1),
+                           "R1": round(float(sizes[3]), 1)},
+        }
+
+    # ---- CPU side by side: the reference-faithful restatement on this box's host cores ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu_baseline = cpu_port_baseline(graph, table.cpu(), w1.cpu(), w2.cpu(), candidates, k1, k2, concat, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "node-embeddings/sec (2-hop forward)", "value": round(value, 1), "unit": "embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: R-MAT 2^{args.scale} nodes / {args.edges} edges, {d0}-dim fp32 features, "
+                                   f"2-layer GraphSAGE-mean {args.mode} encoder H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU",
+                       "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
+                       "streams_in_flight": nstreams, "fused_layers": not args.unfused,
+                       "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
+            "parity_max_err_vs_fp64_oracle": parity_err,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_port_baseline(graph, table, w1, w2, candidates, k1, k2, concat, budget_s):
+    """oracle/ref_dense.py (Python set sampling + dense mask + div + mm: the reference's algorithm,
+    pinned to it by tests/golden) timed on the host cores.  Bounded sample: B = 256 forwards until
+    `budget_s` seconds of CPU work (the dense mask of a B = 4096 batch is 10 GB)."""
+    from oracle import ref_dense
+
+    class LazyAdj(dict):          # adjacency sets built on first touch; warmed before timing
+        def __missing__(self, v):
+            s = set(int(x) for x in graph.neighbors(v))
+            self[v] = s
+            return s
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    adj = LazyAdj()
+    bs = 256
+    rs = np.random.default_rng(12345)
+    batches = [[int(x) for x in rs.choice(candidates, bs, replace=False)] for _ in range(64)]
+
+    def forward(i):
+        random.seed(1000 + i)
+        with torch.no_grad():
+            return ref_dense.two_hop_forward(batches[i], adj, adj, table, w1, w2, k1, k2, not concat)
+
+    forward(0)
+    t0 = time.perf_counter()
+    forward(0)
+    one = time.perf_counter() - t0
+    reps = int(max(2, min(len(batches), budget_s / max(one, 1e-3) / 2)))
+    for i in range(reps):          # warm pass: builds the sets these exact batches touch
+        forward(i)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        forward(i)
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * reps / dt, 1), "unit": "embeddings/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} forwards of B={bs} seeds on the same graph/features/weights/fanout, "
+                      f"{dt:.1f} s of CPU work, oracle/ref_dense.py (dense-mask algorithm of the reference)",
+            "ms_per_forward": round(dt / reps * 1e3, 2)}
+
+
+if __name__ == "__main__":
+    main()

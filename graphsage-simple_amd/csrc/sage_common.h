@@ -1,0 +1,91 @@
+// Shared host/device helpers for libsage355 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "sage355.h"
+
+// ---- error plumbing (host) --------------------------------------------------
+void sage_set_error(const char* fmt, ...);
+
+#define SAGE_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            sage_set_error(__VA_ARGS__);   \
+            return SAGE_EINVAL;            \
+        }                                  \
+    } while (0)
+
+#define SAGE_CHECK_LAUNCH(what)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            sage_set_error("%s: %s", what, hipGetErrorString(e_));                \
+            return SAGE_ELAUNCH;                                                  \
+        }                                                                         \
+    } while (0)
+
+static inline bool sage_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline int sage_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kNumCU = 256;        // MI355X
+
+// ---- Philox4x32-10 (device + host; oracle/sampler_ref.c restates it) -----------
+struct Philox4 { uint32_t v[4]; };
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// uniform integer in [0, bound) from one 32-bit draw (multiply-shift; bias < bound / 2^32)
+__host__ __device__ inline uint32_t sage_bounded(uint32_t r, uint32_t bound) {
+    return (uint32_t)(((uint64_t)r * (uint64_t)bound) >> 32);
+}
+
+// ---- frontier hash ------------------------------------------------------------
+__host__ __device__ inline uint32_t sage_hash_slot(uint32_t id, uint32_t mask) {
+    uint32_t h = id * 0x9E3779B1u;
+    h ^= h >> 15;
+    return h & mask;
+}
+
+#ifdef __HIPCC__
+// Insert `id`; returns the slot holding it and whether THIS call claimed the slot.
+// Terminates because capacity >= 2 x max distinct ids (checked on the host).
+__device__ inline int sage_hash_insert(int32_t* __restrict__ keys, uint32_t mask, int32_t id, bool& won) {
+    uint32_t slot = sage_hash_slot((uint32_t)id, mask);
+    won = false;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const int32_t seen = atomicCAS(&keys[slot], -1, id);
+        if (seen == -1) { won = true; return (int)slot; }
+        if (seen == id) return (int)slot;
+        slot = (slot + 1) & mask;
+    }
+    return -1;  // table full: unreachable with a correctly sized table
+}
+
+__device__ inline int sage_lane() { return (int)(threadIdx.x & (kWave - 1)); }
+
+__device__ inline float sage_activate(float v, int act) {
+    if (act == SAGE_ACT_RELU) return v < 0.f ? 0.f : v;             // NaN stays NaN (torch.relu)
+    if (act == SAGE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+#endif

@@ -1,0 +1,183 @@
+// Two-layer ("2-hop") forward: graphsage/model.py:219-222 wiring of two Encoders,
+// enqueued on one stream with no host synchronisation.
+//
+//   seeds --sample k2 (enc2.adj)--> nbr2 --hash--> frontier U2 = layer-1 node list S1
+//   S1    --sample k1 (enc1.adj)--> nbr1
+//   layer 1 on S1 : h1 = act1( [table[S1] |] mean(table[nbr1]) . W1^T )     (encoders.py:47-62)
+//   layer 2 on B  : out = act2( [h1[seed] |] mean(h1[row(nbr2)]) . W2^T )
+//
+// Concat encoder (gcn=False): the reference evaluates layer 1 a SECOND time on the seeds
+// (self_feats = features(nodes), encoders.py:49-52) with samples of its own; those B rows
+// sit at the head of S1 (rows [0,B)) and draw from RNG stream SAGE_TAG_INNER_SELF, the
+// frontier rows follow from row B.
+#include <string.h>
+
+#include "sage_internal.h"
+
+namespace {
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int next_pow2(int64_t x) {
+    int64_t p = 4;
+    while (p < x) p <<= 1;
+    return (int)p;
+}
+
+int check_model(const sage_model_t* m) {
+    SAGE_REQUIRE(m, "forward2: NULL model");
+    SAGE_REQUIRE(m->num_nodes > 0 && m->num_nodes < (1ll << 31), "forward2: num_nodes = %lld", (long long)m->num_nodes);
+    SAGE_REQUIRE(m->d0 >= 1 && m->h1 >= 1 && m->h2 >= 1, "forward2: dims d0=%d h1=%d h2=%d", m->d0, m->h1, m->h2);
+    SAGE_REQUIRE(m->k1 >= 1 && m->k1 <= SAGE_MAX_FANOUT && m->k2 >= 1 && m->k2 <= SAGE_MAX_FANOUT,
+                 "forward2: fanouts k1=%d k2=%d outside [1, %d]", m->k1, m->k2, SAGE_MAX_FANOUT);
+    SAGE_REQUIRE(m->table_ld >= m->d0, "forward2: table_ld = %lld < d0", (long long)m->table_ld);
+    SAGE_REQUIRE(m->act1 >= 0 && m->act1 <= SAGE_ACT_NONE && m->act2 >= 0 && m->act2 <= SAGE_ACT_NONE, "forward2: bad activation");
+    return SAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sage_ws_layout_t* L) {
+    if (int rc = check_model(m)) return rc;
+    SAGE_REQUIRE(L, "forward2_layout: NULL layout");
+    SAGE_REQUIRE(max_batch >= 1 && (int64_t)max_batch * (m->k2 + 1) < (1ll << 30), "forward2_layout: max_batch = %d", max_batch);
+    memset(L, 0, sizeof(*L));
+    const int64_t B = max_batch;
+    const int64_t max_s1 = B * m->k2 + B;   // frontier of B*k2 ids + B self rows (concat or self-loop)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L->counters = take(8 * sizeof(int32_t));
+    L->hash_capacity = next_pow2(2 * B * (m->k2 + 1));
+    L->hash_keys = take((size_t)L->hash_capacity * 4);
+    L->hash_rows = take((size_t)L->hash_capacity * 4);
+    L->max_s1 = (int32_t)max_s1;
+    L->s1_nodes = take((size_t)max_s1 * 4);
+    L->nbr2 = take((size_t)B * m->k2 * 4);
+    L->slot2 = take((size_t)B * m->k2 * 4);
+    L->cnt2 = take((size_t)B * 4);
+    L->self_slot2 = take((size_t)B * 4);
+    L->nbr1 = take((size_t)max_s1 * m->k1 * 4);
+    L->cnt1 = take((size_t)max_s1 * 4);
+    L->agg1 = take((size_t)max_s1 * m->d0 * 4);
+    L->h1 = take((size_t)max_s1 * m->h1 * 4);
+    L->agg2 = take((size_t)B * m->h1 * 4);
+    L->total_bytes = off;
+    return SAGE_OK;
+}
+
+namespace {
+// ev: NULL, or 2*SAGE_NUM_STAGES hipEvent_t (begin, end per stage; NULL entries skipped)
+#define SAGE_EV(i)                                                                         \
+    do {                                                                                   \
+        if (ev && ev[i] && hipEventRecord((hipEvent_t)ev[i], st) != hipSuccess) {          \
+            sage_set_error("forward2: hipEventRecord failed");                             \
+            return SAGE_ELAUNCH;                                                           \
+        }                                                                                  \
+    } while (0)
+
+int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
+                  uint64_t seed, float* out, int64_t ldo, sage_stream_t stream, void* const* ev) {
+    if (int rc = check_model(m)) return rc;
+    SAGE_REQUIRE(m->rowptr1 && m->col1 && m->rowptr2 && m->col2 && m->table && m->w1 && m->w2, "forward2: NULL model array");
+    SAGE_REQUIRE(workspace && seeds && out, "forward2: NULL argument");
+    SAGE_REQUIRE(batch >= 1, "forward2: batch = %d", batch);
+    SAGE_REQUIRE(ldo >= m->h2, "forward2: ldo = %lld < h2", (long long)ldo);
+    SAGE_REQUIRE(sage_aligned(workspace, 256), "forward2: workspace not 256-byte aligned");
+    sage_ws_layout_t L;
+    if (int rc = sage_forward2_layout(m, batch, &L)) return rc;
+    if (L.total_bytes > workspace_bytes) {
+        sage_set_error("forward2: workspace %zu bytes < %zu needed for batch %d", workspace_bytes, L.total_bytes, batch);
+        return SAGE_ENOSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int32_t* counters = (int32_t*)(ws + L.counters);
+    int32_t* s1_count = counters + 0;
+    int32_t* any2 = counters + 1;
+    int32_t* any1 = counters + 2;
+    int32_t* s1_nodes = (int32_t*)(ws + L.s1_nodes);
+    int32_t* nbr2 = (int32_t*)(ws + L.nbr2);
+    int32_t* slot2 = (int32_t*)(ws + L.slot2);
+    int32_t* cnt2 = (int32_t*)(ws + L.cnt2);
+    int32_t* self_slot2 = (int32_t*)(ws + L.self_slot2);
+    int32_t* nbr1 = (int32_t*)(ws + L.nbr1);
+    int32_t* cnt1 = (int32_t*)(ws + L.cnt1);
+    float* agg1 = (float*)(ws + L.agg1);
+    float* h1 = (float*)(ws + L.h1);
+    float* agg2 = (float*)(ws + L.agg2);
+    const sage_frontier_t fr{(int32_t*)(ws + L.hash_keys), (int32_t*)(ws + L.hash_rows), L.hash_capacity, s1_nodes, s1_count, L.max_s1};
+    const int first_row = m->concat ? batch : 0;
+    const int self_loop = m->agg_self_loop ? 1 : 0;
+
+    if (hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), st) != hipSuccess) { sage_set_error("forward2: memset failed"); return SAGE_ELAUNCH; }
+    if (int rc = sage_frontier_reset(&fr, first_row, st)) return rc;
+    if (m->concat) {
+        if (hipMemcpyAsync(s1_nodes, seeds, (size_t)batch * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            sage_set_error("forward2: seed copy failed");
+            return SAGE_ELAUNCH;
+        }
+    }
+    // outer hop: seeds -> nbr2 (+ frontier)
+    SAGE_EV(0);
+    if (int rc = sage_launch_sample(m->rowptr2, m->col2, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
+                                    cnt2, any2, &fr, self_loop, slot2, self_slot2, st))
+        return rc;
+    SAGE_EV(1);
+    // inner hop: S1 -> nbr1 (raw table rows; no dedupe needed, duplicates are served by L2 / Infinity Cache)
+    SAGE_EV(2);
+    if (int rc = sage_launch_sample(m->rowptr1, m->col1, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
+                                    SAGE_TAG_INNER_SELF, nbr1, cnt1, any1, nullptr, 0, nullptr, nullptr, st))
+        return rc;
+    SAGE_EV(3);
+    const int32_t* nan1 = m->nan_empty ? any1 : nullptr;
+    const int32_t* nan2 = m->nan_empty ? any2 : nullptr;
+    const int64_t ldw1 = (int64_t)m->d0 * (m->concat ? 2 : 1);
+    const int64_t ldw2 = (int64_t)m->h1 * (m->concat ? 2 : 1);
+    // layer 1 on S1
+    SAGE_EV(4);
+    const bool fuse1 = m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat);
+    if (fuse1) {
+        if (int rc = sage_launch_layer_fused(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
+                                             self_loop ? s1_nodes : nullptr, nan1, m->concat, s1_nodes, m->w1, ldw1, m->h1, m->act1,
+                                             h1, m->h1, st))
+            return rc;
+    } else {
+        if (int rc = sage_launch_gather_mean(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
+                                             self_loop ? s1_nodes : nullptr, nan1, agg1, m->d0, st))
+            return rc;
+        if (int rc = sage_launch_linear_act(m->concat ? m->table : nullptr, m->table_ld, s1_nodes, agg1, m->d0, m->d0, m->w1, ldw1,
+                                            m->h1, m->act1, L.max_s1, s1_count, h1, m->h1, st))
+            return rc;
+    }
+    SAGE_EV(5);
+    // layer 2 on the seeds
+    SAGE_EV(6);
+    const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat);
+    if (fuse2) {
+        if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, slot2, cnt2, m->k2, batch, nullptr, fr.rows,
+                                             self_loop ? self_slot2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
+                                             out, ldo, st))
+            return rc;
+    } else {
+        if (int rc = sage_launch_gather_mean(h1, L.max_s1, m->h1, m->h1, slot2, cnt2, m->k2, batch, nullptr, fr.rows,
+                                             self_loop ? self_slot2 : nullptr, nan2, agg2, m->h1, st))
+            return rc;
+        if (int rc = sage_launch_linear_act(m->concat ? h1 : nullptr, m->h1, nullptr, agg2, m->h1, m->h1, m->w2, ldw2, m->h2, m->act2,
+                                            batch, nullptr, out, ldo, st))
+            return rc;
+    }
+    SAGE_EV(7);
+    return SAGE_OK;
+}
+}  // namespace
+
+extern "C" int sage_forward2(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
+                             uint64_t seed, float* out, int64_t ldo, sage_stream_t stream) {
+    return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, stream, nullptr);
+}
+
+extern "C" int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds,
+                                      int32_t batch, uint64_t seed, float* out, int64_t ldo, sage_stream_t stream,
+                                      void* const* stage_events) {
+    return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, stream, stage_events);
+}

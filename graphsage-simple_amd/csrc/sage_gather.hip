@@ -1,0 +1,123 @@
+// gather_mean: per-row mean of gathered feature rows (two-launch form).
+//
+// Replaces aggregators.py:54-74 -- the dense [B,U] 0/1 mask, its two normalisation
+// passes, the frontier feature fetch and mask.mm(embed_matrix) -- by reading exactly
+// the sampled rows.  HBM-bound: algorithmic bytes per destination row = 4*dim*cnt
+// gathered + 4*dim written.  One wavefront per destination row; a lane
+// owns 4 consecutive columns (16-B loads, 1 KiB per wave-instruction = one 256-float
+// row), neighbour ids are broadcast from a VGPR with v_readlane so every row address
+// is scalar; the j-loop is unrolled so 8 row loads are in flight per wave.
+#include "sage_common.h"
+
+namespace {
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+__device__ inline void vadd(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ inline void vadd(float& a, const float& b) { a += b; }
+__device__ inline float4 vscale(const float4& a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ inline float vscale(const float& a, float s) { return a * s; }
+__device__ inline void vfill(float4& a, float s) { a = make_float4(s, s, s, s); }
+__device__ inline void vfill(float& a, float s) { a = s; }
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_mean_kernel(
+    const float* __restrict__ table, int table_rows, int64_t ld, int dim,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
+    const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
+    float* __restrict__ out, int64_t ldo) {
+    using V = typename VecT<VEC>::type;
+    int nn = n;
+    if (n_dev) nn = min(*n_dev, n);
+    const int lane = sage_lane();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const bool nan_rule = any_nonempty ? (*any_nonempty != 0) : false;
+    const int last_row = table_rows - 1;
+
+    for (int r = wave; r < nn; r += nwaves) {
+        const int c = __builtin_amdgcn_readfirstlane(cnt[r]);
+        int s = -1;
+        if (self_row) {
+            s = self_row[r];
+            if (slot_rows && s >= 0) s = slot_rows[s];
+            s = __builtin_amdgcn_readfirstlane(s);
+        }
+        // is the self row already among the sampled ones?  (aggregators.py:50-51: set union)
+        bool extra = s >= 0;
+        if (extra) {
+            for (int base = 0; base < c; base += kWave) {
+                int id = (base + lane < c) ? nbr[(int64_t)r * k + base + lane] : -1;
+                if (slot_rows && id >= 0) id = slot_rows[id];
+                if (__any(id == s)) extra = false;
+            }
+        }
+        const int ceff = c + (extra ? 1 : 0);
+        const float inv = 1.0f / (float)ceff;
+
+        for (int cb = 0; cb < dim; cb += kWave * VEC) {
+            const int c0 = cb + lane * VEC;
+            const bool ok = c0 < dim;
+            V acc;
+            vfill(acc, 0.f);
+            for (int base = 0; base < c; base += kWave) {
+                const int m = min(kWave, c - base);
+                int myid = (lane < m) ? nbr[(int64_t)r * k + base + lane] : 0;
+                if (slot_rows) myid = slot_rows[max(myid, 0)];
+                myid = min(max(myid, 0), last_row);      // never fault on a bad id
+                // 8 row loads in flight per wave; the tail re-reads row m-1 (an L1 hit) with weight 0
+                for (int j0 = 0; j0 < m; j0 += 8) {
+                    V t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int id = __builtin_amdgcn_readlane(myid, min(j0 + u, m - 1));
+                        if (ok) t[u] = *reinterpret_cast<const V*>(table + (int64_t)id * ld + c0);
+                        else vfill(t[u], 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < m) vadd(acc, t[u]);
+                }
+            }
+            if (extra && ok) vadd(acc, *reinterpret_cast<const V*>(table + (int64_t)min(s, last_row) * ld + c0));
+            if (ok) {
+                V res;
+                if (ceff > 0) res = vscale(acc, inv);
+                else vfill(res, nan_rule ? __builtin_nanf("") : 0.f);
+                *reinterpret_cast<V*>(out + (int64_t)r * ldo + c0) = res;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
+                            const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
+                            const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, hipStream_t st) {
+    if (n == 0) return SAGE_OK;
+    const int blocks = min(sage_cdiv(n, 4), kNumCU * 8);
+    const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
+    if (vec4)
+        hipLaunchKernelGGL(gather_mean_kernel<4>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n,
+                           n_dev, slot_rows, self_row, any_nonempty, out, ldo);
+    else
+        hipLaunchKernelGGL(gather_mean_kernel<1>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n,
+                           n_dev, slot_rows, self_row, any_nonempty, out, ldo);
+    SAGE_CHECK_LAUNCH("gather_mean_kernel");
+    return SAGE_OK;
+}
+
+extern "C" int sage_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
+                                const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
+                                const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo,
+                                sage_stream_t stream) {
+    SAGE_REQUIRE(table && nbr && cnt && out, "gather_mean: NULL array");
+    SAGE_REQUIRE(n >= 0 && k >= 1, "gather_mean: n = %d, k = %d", n, k);
+    SAGE_REQUIRE(dim >= 1 && ld >= dim && ldo >= dim, "gather_mean: dim = %d, ld = %lld, ldo = %lld", dim, (long long)ld, (long long)ldo);
+    SAGE_REQUIRE(table_rows >= 1 && table_rows < (1ll << 31), "gather_mean: table_rows = %lld", (long long)table_rows);
+    return sage_launch_gather_mean(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo,
+                                   (hipStream_t)stream);
+}

@@ -1,0 +1,184 @@
+"""Encoder -- host-side mirror of graphsage/encoders.py:8-62.
+
+Same constructor, attributes, parameter name (``weight``) and ``forward(nodes)
+-> [embed_dim, len(nodes)]`` as the reference class; ``model.py`` can build its
+two-layer stack from it unchanged (model.py:218-222).  Underneath:
+
+* the adjacency dict-of-sets is converted ONCE to CSR in HBM (graph.py);
+* ``features`` being an ``nn.Embedding`` means "raw feature table": its weight
+  is kept resident in HBM;
+* ``features`` being ``lambda nodes: enc1(nodes).t()`` with ``base_model=enc1``
+  (exactly how model.py:220-222 wires layer 2) means "the layer below": the
+  whole 2-hop forward then runs as one C call (engine.TwoHopEngine ->
+  sage_forward2) -- sample, frontier dedupe, sample, layer 1, layer 2 -- with
+  no Python in between.  This assumes ``features(ids) == base_model(ids).t()``;
+  pass ``fuse_base_model=False`` for a base model wired differently.
+* anything else is treated as an opaque feature function: the frontier ids are
+  handed to it (as the reference does, aggregators.py:62-65) and the returned
+  rows are aggregated on the GPU.
+
+Sampling: the device sampler draws k distinct uniform neighbours per node
+(all of them when deg < k), the reference's rule (aggregators.py:42-46), from a
+counter-based generator.  Each ``forward`` takes ONE 64-bit value from Python's
+global ``random`` as its key, so ``random.seed(s)`` (model.py:193) still makes a
+run reproducible, but the sets differ from the reference's for the same seed.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from . import autograd, native, ops
+from .aggregators import MeanAggregator
+from .engine import TwoHopEngine
+from .graph import csr_from_adj_lists
+
+SIGMOID_INITIALIZERS = ("node_degree", "shared", "pagerank")   # encoders.py:58
+
+_csr_cache = {}
+
+
+def _device_csr(adj_lists, num_nodes_hint, device):
+    """dict-of-sets -> CSR in HBM, cached per adjacency object (both layers share one, model.py:219-222)."""
+    key = id(adj_lists)
+    hit = _csr_cache.get(key)
+    if hit is not None and hit[0] is adj_lists:
+        return hit[1], hit[2]
+    g = csr_from_adj_lists(adj_lists, None)
+    if num_nodes_hint and g.num_nodes < num_nodes_hint:
+        pad = np.full(num_nodes_hint - g.num_nodes, g.rowptr[-1], dtype=np.int64)
+        g.rowptr = np.concatenate([g.rowptr, pad])
+        g.num_nodes = num_nodes_hint
+    rowptr, col = g.to(device)
+    if col.numel() == 0:
+        col = torch.zeros(1, dtype=torch.int32, device=device)
+    _csr_cache[key] = (adj_lists, rowptr, col)
+    return rowptr, col
+
+
+class Encoder(nn.Module):
+    """Encodes a node using the 'convolutional' GraphSage approach"""
+
+    def __init__(self, features, feature_dim, embed_dim, adj_lists, aggregator, num_sample=10, initializer="None",
+                 base_model=None, gcn=False, cuda=False, feature_transform=False, fuse_base_model=True):
+        super(Encoder, self).__init__()
+        self.features = features
+        self.feat_dim = feature_dim
+        self.adj_lists = adj_lists
+        self.aggregator = aggregator
+        self.num_sample = num_sample
+        if base_model != None:   # noqa: E711  (encoders.py:24)
+            self.base_model = base_model
+        self.gcn = gcn
+        self.embed_dim = embed_dim
+        self.cuda = cuda                       # shadows nn.Module.cuda, as encoders.py:29 does
+        self.aggregator.cuda = cuda            # encoders.py:30
+        self.weight = nn.Parameter(torch.FloatTensor(embed_dim, self.feat_dim if self.gcn else 2 * self.feat_dim))
+        self.initializer = initializer
+        init.xavier_uniform_(self.weight)
+        self.fuse_base_model = fuse_base_model
+        self._engine = None
+        self._engine_key = None
+        self._dev_cache = {}
+        print("feat dim:", self.feat_dim, "embed_dim:", self.embed_dim)   # encoders.py:38
+
+    # ------------------------------------------------------------------ helpers
+    def _act(self):
+        return ops.ACT_SIGMOID if self.initializer in SIGMOID_INITIALIZERS else ops.ACT_RELU
+
+    def _on_device(self, t, tag):
+        """Device-resident copy of a host tensor, refreshed when the tensor is modified in place."""
+        if t.is_cuda:
+            return t
+        key = (tag, t.data_ptr(), t._version, tuple(t.shape))
+        hit = self._dev_cache.get(tag)
+        if hit is None or hit[0] != key:
+            hit = (key, t.detach().to("cuda", torch.float32).contiguous())
+            self._dev_cache[tag] = hit
+        return hit[1]
+
+    def _weight_dev(self):
+        w = self.weight
+        if w.is_cuda:
+            return w
+        if torch.is_grad_enabled() and w.requires_grad:
+            return w.to("cuda")            # differentiable copy: the gradient flows back to the host Parameter
+        return self._on_device(w, "weight")
+
+    def _is_table(self):
+        return isinstance(self.features, nn.Embedding)
+
+    def _agg_self_loop(self):
+        return bool(getattr(self.aggregator, "gcn", False))
+
+    def _can_fuse_two_hop(self):
+        base = getattr(self, "base_model", None)
+        return (self.fuse_base_model and isinstance(base, Encoder) and base._is_table()
+                and isinstance(self.aggregator, MeanAggregator) and isinstance(base.aggregator, MeanAggregator)
+                and self.gcn == base.gcn and self._agg_self_loop() == base._agg_self_loop()
+                and self.num_sample is not None and base.num_sample is not None
+                and 1 <= self.num_sample <= native.MAX_FANOUT and 1 <= base.num_sample <= native.MAX_FANOUT)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, nodes):
+        """Generates embeddings for a batch of nodes.  nodes -- list / array / LongTensor of node ids.
+        -> FloatTensor [embed_dim, len(nodes)] (encoders.py:62)"""
+        if not torch.cuda.is_available():
+            raise native.SageError("sage355.Encoder needs an MI355X; there is no CPU path")
+        native.lib()
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self._can_fuse_two_hop() and not training:
+            out = self._forward_two_hop(nodes)
+        elif self._is_table() and self.num_sample is not None and self.num_sample <= native.MAX_FANOUT \
+                and isinstance(self.aggregator, MeanAggregator):
+            out = self._forward_table(nodes)
+        else:
+            out = self._forward_generic(nodes)
+        out = out.t()
+        return out if self.cuda else out.cpu()
+
+    def _forward_two_hop(self, nodes):
+        base = self.base_model
+        dev = torch.device("cuda")
+        table = base._on_device(base.features.weight, "table")
+        n = table.shape[0]
+        rp1, c1 = _device_csr(base.adj_lists, n, dev)
+        rp2, c2 = _device_csr(self.adj_lists, n, dev)
+        w1, w2 = base._weight_dev().detach(), self._weight_dev().detach()
+        key = (rp1.data_ptr(), rp2.data_ptr(), table.data_ptr(), w1.data_ptr(), w2.data_ptr(), base.num_sample,
+               self.num_sample, self.gcn, self._agg_self_loop(), base._act(), self._act())
+        if self._engine is None or self._engine_key != key:
+            self._engine = TwoHopEngine(rp1, c1, table, w1, w2, base.num_sample, self.num_sample, concat=not self.gcn,
+                                        agg_self_loop=self._agg_self_loop(), act1=base._act(), act2=self._act(),
+                                        nan_empty=True, max_batch=max(len(nodes), 256), rowptr_outer=rp2, col_outer=c2)
+            self._engine_key = key
+        return self._engine.forward(nodes, seed=random.getrandbits(64))
+
+    def _forward_table(self, nodes):
+        """One layer over a raw feature table (encoders.py:47-62 with features = nn.Embedding)."""
+        dev = torch.device("cuda")
+        table = self._on_device(self.features.weight, "table")
+        rowptr, col = _device_csr(self.adj_lists, table.shape[0], dev)
+        ids = ops.as_ids(nodes, dev)
+        any_nonempty = torch.zeros(1, dtype=torch.int32, device=dev)
+        nbr, cnt, _, _ = ops.sample_neighbors(rowptr, col, ids, self.num_sample, random.getrandbits(64), ops.TAG_INNER,
+                                              any_nonempty=any_nonempty)
+        self_row = ids if self._agg_self_loop() else None
+        w = self._weight_dev()
+        agg = autograd.gather_mean(table, nbr, cnt, any_nonempty, None, self_row)
+        return autograd.linear_act(agg, w, self._act(), None if self.gcn else table, None if self.gcn else ids)
+
+    def _forward_generic(self, nodes):
+        """Opaque feature function / foreign aggregator: the reference's own call sequence
+        (encoders.py:47-56) with the aggregation and the contraction on the GPU."""
+        node_list = [int(n) for n in nodes]
+        neigh_feats = self.aggregator.forward(node_list, [self.adj_lists[n] for n in node_list], self.num_sample,
+                                              initializer=self.initializer)
+        neigh_feats = neigh_feats.to("cuda", torch.float32)
+        self_feats = None
+        if not self.gcn:
+            ids = torch.LongTensor(node_list)
+            self_feats = self.features(ids.cuda() if self.cuda else ids).to("cuda", torch.float32).contiguous()
+        return autograd.linear_act(neigh_feats.contiguous(), self._weight_dev(), self._act(), self_feats, None)

@@ -1,0 +1,122 @@
+"""TwoHopEngine: the 2-layer forward of graphsage/model.py:219-222 as ONE C call.
+
+Everything the reference rebuilds per batch in Python (adjacency lookups, set
+sampling, set union, id->column dict, dense mask) is device resident here:
+CSR adjacency, the fp32 feature table and both weight matrices stay in HBM, and
+`forward` enqueues sample -> frontier -> sample -> layer 1 -> layer 2 on the
+current stream without a host round trip (sage_forward2, include/sage355.h).
+"""
+import torch
+
+from . import native
+from .ops import ACT_RELU, _chk, _need_gpu, _row_major, as_ids
+
+
+class TwoHopEngine:
+    def __init__(self, rowptr, col, table, w1, w2, k1, k2, concat=False, agg_self_loop=False, act1=ACT_RELU,
+                 act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None):
+        """rowptr/col: CSR of enc1.adj_lists (inner hop); rowptr_outer/col_outer: CSR of
+        enc2.adj_lists when it differs (injected pre-sampled sets), default the same.
+        w1 [h1, d0 | 2*d0], w2 [h2, h1 | 2*h1]: the Encoders' `weight` Parameters
+        (referenced, not copied: an optimizer step is seen by the next forward)."""
+        _need_gpu()
+        self.rowptr1 = _chk(rowptr, torch.int64, "rowptr", 1)
+        self.col1 = _chk(col, torch.int32, "col", 1)
+        self.rowptr2 = self.rowptr1 if rowptr_outer is None else _chk(rowptr_outer, torch.int64, "rowptr_outer", 1)
+        self.col2 = self.col1 if col_outer is None else _chk(col_outer, torch.int32, "col_outer", 1)
+        if self.rowptr2.shape[0] != self.rowptr1.shape[0]:
+            raise native.SageError("inner and outer CSR must cover the same node ids")
+        self.table, self.table_ld = _row_major(table, "table")
+        self.num_nodes = self.rowptr1.shape[0] - 1
+        if self.table.shape[0] < self.num_nodes:
+            raise native.SageError(f"table has {self.table.shape[0]} rows for {self.num_nodes} nodes")
+        self.w1, self.w2 = w1, w2
+        self.d0 = self.table.shape[1]
+        self.h1, self.h2 = w1.shape[0], w2.shape[0]
+        mult = 2 if concat else 1
+        if tuple(w1.shape) != (self.h1, mult * self.d0) or tuple(w2.shape) != (self.h2, mult * self.h1):
+            raise native.SageError(f"weight shapes {tuple(w1.shape)}, {tuple(w2.shape)} do not fit d0={self.d0}, concat={concat}")
+        self.k1, self.k2 = int(k1), int(k2)
+        self.concat, self.agg_self_loop = bool(concat), bool(agg_self_loop)
+        self.act1, self.act2 = int(act1), int(act2)
+        self.nan_empty, self.fused = bool(nan_empty), bool(fused)
+        self.device = self.table.device
+        self.max_batch = 0
+        self.workspace = None
+        self.layout = native.WsLayout()
+        self._model_key = None
+        self._model_c = None
+        self._last_batch = 0
+        self._reserve(max_batch)
+
+    def _model(self):
+        w1, w2 = self.w1, self.w2
+        key = (w1.data_ptr(), w2.data_ptr())
+        if self._model_key == key:
+            return self._model_c
+        _row_major(w1.detach(), "w1")
+        _row_major(w2.detach(), "w2")
+        if not (w1.is_contiguous() and w2.is_contiguous()):
+            raise native.SageError("weights must be contiguous")
+        self._model_c = native.Model(
+            self.rowptr1.data_ptr(), self.col1.data_ptr(), self.rowptr2.data_ptr(), self.col2.data_ptr(), self.num_nodes,
+            self.table.data_ptr(), self.table_ld, self.d0, w1.data_ptr(), self.h1, w2.data_ptr(), self.h2, self.k1, self.k2,
+            int(self.concat), int(self.agg_self_loop), self.act1, self.act2, int(self.nan_empty), int(self.fused))
+        self._model_key = key
+        return self._model_c
+
+    def _reserve(self, batch):
+        if batch <= self.max_batch:
+            return
+        lay = native.WsLayout()
+        native.check(native.lib().sage_forward2_layout(self._model(), int(batch), lay), "forward2_layout")
+        self.workspace = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)
+        self.max_batch = int(batch)
+
+    def forward(self, seeds, seed=0, out=None, stage_events=None):
+        """seeds: int32 device tensor (or anything as_ids takes) -> out [B, h2] on device.
+        `seed` keys the sampler: the sets are a pure function of (seed, node id, hop).
+        stage_events: optional (c_void_p * 8) of hipEvent_t recorded around the four stages."""
+        if not (isinstance(seeds, torch.Tensor) and seeds.is_cuda and seeds.dtype == torch.int32 and seeds.is_contiguous()):
+            seeds = as_ids(seeds, self.device)
+        b = seeds.shape[0]
+        if b > self.max_batch:
+            self._reserve(b)
+        if out is None:
+            out = torch.empty((b, self.h2), dtype=torch.float32, device=self.device)
+        elif out.shape != (b, self.h2) or out.dtype != torch.float32 or not out.is_cuda or out.stride(1) != 1:
+            raise native.SageError("forward: `out` must be a [B, h2] fp32 device tensor with unit inner stride")
+        L = native.lib()
+        args = (self._model(), self.workspace.data_ptr(), self.workspace.numel(), seeds.data_ptr(), b,
+                int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream)
+        rc = L.sage_forward2(*args) if stage_events is None else L.sage_forward2_profiled(*args, stage_events)
+        if rc != 0:
+            native.check(rc, "forward2")
+        self._last_batch = b
+        return out
+
+    # ---- read-back of the last forward's intermediates (tests, parity gate, byte counting) ----
+    def _view(self, off, count, dtype):
+        itemsize = torch.empty(0, dtype=dtype).element_size()
+        return self.workspace[off: off + count * itemsize].view(dtype)
+
+    def intermediates(self):
+        """Sampled sets and layer-1 state of the LAST forward (synchronises)."""
+        L, b = self.layout, self._last_batch
+        native.check(native.lib().sage_forward2_layout(self._model(), b, L), "forward2_layout")
+        torch.cuda.synchronize()
+        counters = self._view(L.counters, 8, torch.int32).cpu()
+        n1 = int(counters[0])
+        first = b if self.concat else 0
+        s1 = self._view(L.s1_nodes, L.max_s1, torch.int32)[:n1]
+        rows = self._view(L.hash_rows, L.hash_capacity, torch.int32)
+        slot2 = self._view(L.slot2, b * self.k2, torch.int32).view(b, self.k2)
+        return {
+            "n_s1": n1, "first_frontier_row": first, "s1_nodes": s1,
+            "nbr2": self._view(L.nbr2, b * self.k2, torch.int32).view(b, self.k2),
+            "cnt2": self._view(L.cnt2, b, torch.int32),
+            "row2": rows[slot2.clamp(min=0).long()].masked_fill(slot2 < 0, -1),
+            "nbr1": self._view(L.nbr1, L.max_s1 * self.k1, torch.int32).view(L.max_s1, self.k1)[:n1],
+            "cnt1": self._view(L.cnt1, L.max_s1, torch.int32)[:n1],
+            "h1": self._view(L.h1, L.max_s1 * self.h1, torch.float32).view(L.max_s1, self.h1)[:n1],
+        }

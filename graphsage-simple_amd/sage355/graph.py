@@ -132,26 +132,32 @@ def read_edge_list(path, fmt="pairs"):
     return csr_from_edges(ia, ib, names.size, symmetric=True), names
 
 
-def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24):
+def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, cache_dir=None):
     """Graph500-parameter R-MAT generator: ``num_edges`` directed
-    draws on 2**scale nodes, ``numpy.random.default_rng(seed)``; self loops
-    dropped, symmetrised, deduplicated.  Generated in chunks to bound memory."""
+    draws on 2**scale nodes, ``numpy.random.default_rng(seed)``, one uniform per
+    level choosing the quadrant with probabilities (a, b, c, 1-a-b-c); self loops
+    dropped, symmetrised, deduplicated.  Generated in chunks to bound memory;
+    ``cache_dir`` keeps the CSR as .npy files for later runs on the same box."""
+    import os
+    tag = f"rmat_s{scale}_e{num_edges}_a{a}_b{b}_c{c}_seed{seed}"
+    if cache_dir is not None:
+        fr, fc = os.path.join(cache_dir, tag + "_rowptr.npy"), os.path.join(cache_dir, tag + "_col.npy")
+        if os.path.exists(fr) and os.path.exists(fc):
+            return CSRGraph(np.load(fr), np.load(fc), 1 << scale)
     rng = np.random.default_rng(seed)
     n = 1 << scale
     keys = []
-    ab = a + b
-    c_norm = c / (1.0 - ab)
-    a_norm = a / ab
+    t_ab, t_abc = np.float32(a + b), np.float32(a + b + c)
+    t_a = np.float32(a)
     done = 0
     while done < num_edges:
         m = min(chunk, num_edges - done)
         src = np.zeros(m, dtype=np.int64)
         dst = np.zeros(m, dtype=np.int64)
         for _ in range(scale):
-            r1 = rng.random(m, dtype=np.float32)
-            r2 = rng.random(m, dtype=np.float32)
-            sbit = r1 > ab
-            dbit = r2 > np.where(sbit, c_norm, a_norm).astype(np.float32)
+            u = rng.random(m, dtype=np.float32)
+            sbit = u >= t_ab
+            dbit = ((u >= t_a) & ~sbit) | (u >= t_abc)
             src = (src << 1) | sbit
             dst = (dst << 1) | dbit
         keep = src != dst
@@ -163,7 +169,12 @@ def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24):
     dst = key & (n - 1)
     rowptr = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(np.bincount(src, minlength=n), out=rowptr[1:])
-    return CSRGraph(rowptr, dst.astype(np.int32), n)
+    g = CSRGraph(rowptr, dst.astype(np.int32), n)
+    if cache_dir is not None:
+        os.makedirs(cache_dir, exist_ok=True)
+        np.save(fr, g.rowptr)
+        np.save(fc, g.col)
+    return g
 
 
 def truncate_nodes(g, num_nodes):

@@ -1,0 +1,120 @@
+"""ctypes binding of libsage355.so (C ABI: include/sage355.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every argument
+that crosses the boundary is a raw device pointer, a size or a stream handle.
+There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsage355.so")
+CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
+
+ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
+TAG_INNER, TAG_OUTER, TAG_INNER_SELF = 1, 2, 3
+MAX_FANOUT = 64
+ABI_VERSION = 1
+
+# every symbol include/sage355.h declares (tests check the library exports each one)
+SYMBOLS = [
+    "sage_abi_version", "sage_last_error", "sage_build_arch", "sage_frontier_reset", "sage_sample_neighbors",
+    "sage_frontier_insert", "sage_gather_mean", "sage_linear_act", "sage_layer_forward", "sage_layer_forward_supported",
+    "sage_forward2_layout", "sage_forward2", "sage_forward2_profiled",
+    "sage_linear_act_backward", "sage_gather_mean_backward",
+]
+
+
+class SageError(RuntimeError):
+    pass
+
+
+class Frontier(Structure):
+    _fields_ = [("keys", c_void_p), ("rows", c_void_p), ("capacity", c_int32), ("nodes", c_void_p),
+                ("count", c_void_p), ("max_nodes", c_int32)]
+
+
+class Model(Structure):
+    _fields_ = [("rowptr1", c_void_p), ("col1", c_void_p), ("rowptr2", c_void_p), ("col2", c_void_p),
+                ("num_nodes", c_int64), ("table", c_void_p), ("table_ld", c_int64), ("d0", c_int32),
+                ("w1", c_void_p), ("h1", c_int32), ("w2", c_void_p), ("h2", c_int32),
+                ("k1", c_int32), ("k2", c_int32), ("concat", c_int32), ("agg_self_loop", c_int32),
+                ("act1", c_int32), ("act2", c_int32), ("nan_empty", c_int32), ("fused", c_int32)]
+
+
+class WsLayout(Structure):
+    _fields_ = [("total_bytes", c_size_t), ("counters", c_size_t),
+                ("hash_keys", c_size_t), ("hash_rows", c_size_t), ("hash_capacity", c_int32),
+                ("s1_nodes", c_size_t), ("max_s1", c_int32),
+                ("nbr2", c_size_t), ("slot2", c_size_t), ("cnt2", c_size_t), ("self_slot2", c_size_t),
+                ("nbr1", c_size_t), ("cnt1", c_size_t),
+                ("agg1", c_size_t), ("h1", c_size_t), ("agg2", c_size_t)]
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libsage355.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    res = subprocess.run(["make", "-C", CSRC_DIR, "-j8"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise SageError("building libsage355.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Missing library = hard error (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SageError(f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` "
+                        "(or __graft_entry__.build()); sage355 has no non-HIP path")
+    L = ctypes.CDLL(LIB_PATH)
+    L.sage_abi_version.restype = c_int32
+    L.sage_last_error.restype = c_char_p
+    L.sage_build_arch.restype = c_char_p
+    if L.sage_abi_version() != ABI_VERSION:
+        raise SageError(f"libsage355 ABI {L.sage_abi_version()} != binding ABI {ABI_VERSION}")
+    P, I32, I64 = c_void_p, c_int32, c_int64
+    L.sage_frontier_reset.argtypes = [POINTER(Frontier), I32, P]
+    L.sage_sample_neighbors.argtypes = [P, P, I64, P, I32, P, I32, c_uint64, c_uint32, P, P, P,
+                                        POINTER(Frontier), I32, P, P, P]
+    L.sage_frontier_insert.argtypes = [P, P, I32, P, I32, P, POINTER(Frontier), P, P, P]
+    L.sage_gather_mean.argtypes = [P, I64, I64, I32, P, P, I32, I32, P, P, P, P, P, I64, P]
+    L.sage_linear_act.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, I32, P, P, I64, P]
+    L.sage_layer_forward.argtypes = [P, I64, I64, I32, P, P, I32, I32, P, P, P, P, I32, P, P, I64, I32, I32, P, I64, P]
+    L.sage_layer_forward_supported.argtypes = [I32, I32, I32]
+    L.sage_forward2_layout.argtypes = [POINTER(Model), I32, POINTER(WsLayout)]
+    L.sage_forward2.argtypes = [POINTER(Model), P, c_size_t, P, I32, c_uint64, P, I64, P]
+    L.sage_forward2_profiled.argtypes = [POINTER(Model), P, c_size_t, P, I32, c_uint64, P, I64, P, POINTER(c_void_p)]
+    L.sage_linear_act_backward.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
+                                           P, I64, P, I64, P]
+    L.sage_gather_mean_backward.argtypes = [P, I64, I32, P, P, I32, I32, P, P, P, P, I64, I64, P]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("sage_last_error", "sage_build_arch"):
+            fn.restype = c_int32
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().sage_last_error().decode("utf-8", "replace")
+        raise SageError(f"{what or 'libsage355'} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

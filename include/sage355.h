@@ -1,0 +1,264 @@
+/*
+ * sage355.h -- C ABI of libsage355.so: the GraphSAGE sample -> gather -> masked
+ * mean -> (concat) -> W.x -> act hot path as hand-written HIP kernels for
+ * MI355X (gfx950).
+ *
+ * The reference (zjzijielu/graphsage-simple) is pure Python and has no FFI;
+ * the "operators" of its hot path are the statement groups of
+ *   graphsage/aggregators.py:34-76   MeanAggregator.forward
+ *   graphsage/encoders.py:40-62      Encoder.forward
+ * Each entry point below replaces one such group and cites it.  A maintainer
+ * binds them with ctypes (INTEGRATION.md shows the stub); this repo's own host
+ * side (graphsage-simple_amd/sage355/) does exactly that.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (HBM) unless the name ends in _host.
+ *    The library never allocates, frees or synchronises: the caller owns all
+ *    memory (so a caching allocator and hipGraph capture both work).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - Node ids are int32 (N < 2^31), CSR row pointers int64, features fp32
+ *    row-major with an explicit leading dimension in ELEMENTS.
+ *  - Row counts come in pairs (n, n_dev): `n` is the host-side upper bound used
+ *    to size the launch; if `n_dev` is non-NULL the kernels read the actual
+ *    count from it (min(*n_dev, n)), so a frontier whose size is only known on
+ *    the device needs no host round trip.
+ *  - Return value: SAGE_OK or a negative SAGE_E* code; sage_last_error() gives
+ *    the message for the calling thread.  Arguments are validated on the host
+ *    BEFORE any launch (an out-of-range kernel access can reset the whole
+ *    node), so a call either enqueues all of its kernels or none.
+ */
+#ifndef SAGE355_H
+#define SAGE355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGE_ABI_VERSION 1
+
+#define SAGE_OK            0
+#define SAGE_EINVAL       -1   /* bad argument (NULL, size, alignment, range) */
+#define SAGE_EUNSUPPORTED -2   /* valid request this build has no kernel for  */
+#define SAGE_ELAUNCH      -3   /* hipLaunch / runtime error                   */
+#define SAGE_ENOSPACE     -4   /* workspace too small                         */
+
+#define SAGE_ACT_RELU    0     /* encoders.py:61; NaN propagates like torch.relu */
+#define SAGE_ACT_SIGMOID 1     /* encoders.py:58-59 (node_degree/shared/pagerank) */
+#define SAGE_ACT_NONE    2
+
+#define SAGE_MAX_FANOUT  64    /* device sampler limit on k (BASELINE uses <= 25) */
+
+/* RNG stream tags: which sampling call a draw belongs to (see oracle/sampler_ref.c). */
+#define SAGE_TAG_INNER      1  /* layer-1 samples of the frontier            */
+#define SAGE_TAG_OUTER      2  /* layer-2 samples of the seeds               */
+#define SAGE_TAG_INNER_SELF 3  /* concat encoder: layer-1 samples of the seeds (2nd enc1 call) */
+
+typedef void* sage_stream_t;
+
+int         sage_abi_version(void);
+const char* sage_last_error(void);
+/* Name of the code-object architecture the library was built for ("gfx950"). */
+const char* sage_build_arch(void);
+
+/* ---------------------------------------------------------------------------
+ * Frontier: the set of distinct ids one hop produces, plus id -> row lookup.
+ * Replaces `unique_nodes_list = list(set.union(*samp_neighs))` and the
+ * `unique_nodes` dict (aggregators.py:52-53).  Open-addressing hash in HBM:
+ * keys[slot] = node id (or -1), rows[slot] = position of that id in nodes[].
+ * The ORDER of nodes[] is arbitrary (as a Python set's is); everything
+ * computed from it is order independent.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t* keys;        /* [capacity]  -1 = empty; reset with sage_frontier_reset */
+    int32_t* rows;        /* [capacity]  row of keys[slot] in nodes[]               */
+    int32_t  capacity;    /* power of two, >= 2 * max distinct ids                   */
+    int32_t* nodes;       /* [max_nodes] the distinct ids, arbitrary order           */
+    int32_t* count;       /* [1] device counter: number of rows in nodes[] so far    */
+    int32_t  max_nodes;
+} sage_frontier_t;
+
+/* keys[] := -1, *count := first_row (rows below first_row are reserved by the caller). */
+int sage_frontier_reset(const sage_frontier_t* f, int32_t first_row, sage_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * sage_sample_neighbors -- encoders.py:47 (adjacency fetch) + aggregators.py:42-48
+ * (fixed-fanout sample) [+ aggregators.py:52-53 when `frontier` is given].
+ *
+ * For node v = nodes[r], deg = rowptr[v+1]-rowptr[v]:
+ *   deg >  k : k DISTINCT uniform positions of the CSR row (Floyd's subset
+ *              algorithm, O(k); Philox4x32-10 keyed by `seed`, counter
+ *              (v, tag, draw/4)) -> cnt[r] = k
+ *   deg <= k : the whole row, in CSR order              -> cnt[r] = deg
+ * nbr[r*k + j], j < cnt[r], are global node ids; entries j >= cnt[r] are -1.
+ * The draw for (seed, tag, v) does not depend on r, n or the launch shape.
+ *
+ * frontier != NULL: every sampled id (and v itself when `insert_self`) is
+ * inserted; nbr_slot[r*k+j] receives its hash slot and self_slot[r] the slot of
+ * v.  rows[slot] is valid once this call's kernels have completed (stream
+ * order), so a consumer reads row = frontier->rows[nbr_slot[e]].
+ * any_nonempty (nullable): set to 1 if any cnt[r] > 0 (reference NaN rule).
+ * ------------------------------------------------------------------------- */
+int sage_sample_neighbors(const int64_t* rowptr, const int32_t* col, int64_t num_nodes,
+                          const int32_t* nodes, int32_t n, const int32_t* n_dev,
+                          int32_t k, uint64_t seed, uint32_t tag,
+                          int32_t* nbr, int32_t* cnt, int32_t* any_nonempty,
+                          const sage_frontier_t* frontier, int32_t insert_self,
+                          int32_t* nbr_slot, int32_t* self_slot,
+                          sage_stream_t stream);
+
+/* Insert already-sampled ids (e.g. sets injected by a caller, the reference's
+ * num_sample=None path) into a frontier.  Same outputs as above. */
+int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int32_t k,
+                         const int32_t* self_nodes /* nullable */,
+                         int32_t n, const int32_t* n_dev,
+                         const sage_frontier_t* frontier,
+                         int32_t* nbr_slot, int32_t* self_slot, sage_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * sage_gather_mean -- aggregators.py:54-74: mask build, row normalise, feature
+ * fetch and mask.mm(embed_matrix), without the dense mask:
+ *     out[r, :] = (1/c) * sum_{j<cnt[r]} table[row(nbr[r*k+j]), :]
+ * row(x) = x, or slot_rows[x] when `slot_rows` is given (nbr then holds hash
+ * slots).  self_row (nullable): aggregators.py:50-51 intended semantics -- the
+ * node's own row joins the mean unless it is already among the sampled ones.
+ * cnt[r]==0 (and no self row): NaN row if *any_nonempty != 0 (the reference's
+ * 0/0 inside a mixed batch), else zeros (its all-empty batch); with
+ * any_nonempty == NULL the row is zeros.
+ * ------------------------------------------------------------------------- */
+int sage_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim,
+                     const int32_t* nbr, const int32_t* cnt, int32_t k,
+                     int32_t n, const int32_t* n_dev,
+                     const int32_t* slot_rows, const int32_t* self_row,
+                     const int32_t* any_nonempty,
+                     float* out, int64_t ldo, sage_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * sage_linear_act -- encoders.py:49-62 without materialising the concat:
+ *     out[r, :] = act( W[:, 0:ds] . self(r) + W[:, ds:ds+dim] . agg[r, :] )
+ * self(r) = self_tab[self_index ? self_index[r] : r, 0:dim]; ds = dim when
+ * self_tab != NULL (concat encoder, gcn=False) else 0 (gcn=True).
+ * W is [out_dim, ds+dim] row-major (ldw), exactly the reference Parameter.
+ * out is [n, out_dim] (the module returns its transpose view, encoders.py:62).
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32): exact-fp32 products, fp32 accumulate.
+ * ------------------------------------------------------------------------- */
+int sage_linear_act(const float* self_tab, int64_t ld_self, const int32_t* self_index,
+                    const float* agg, int64_t ld_agg, int32_t dim,
+                    const float* weight, int64_t ldw, int32_t out_dim, int32_t act,
+                    int32_t n, const int32_t* n_dev,
+                    float* out, int64_t ldo, sage_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * sage_layer_forward -- one Encoder.forward (encoders.py:47-62) in ONE launch:
+ * gather-mean rows are staged through an LDS tile and contracted with W by
+ * fp32 MFMA without the [n, dim] round trip through HBM.  Arguments as the two
+ * calls above.  SAGE_EUNSUPPORTED if (dim, out_dim) has no fused kernel; the
+ * caller then uses the two-launch form.
+ * ------------------------------------------------------------------------- */
+int sage_layer_forward(const float* table, int64_t table_rows, int64_t ld, int32_t dim,
+                       const int32_t* nbr, const int32_t* cnt, int32_t k,
+                       int32_t n, const int32_t* n_dev,
+                       const int32_t* slot_rows, const int32_t* self_row,
+                       const int32_t* any_nonempty,
+                       int32_t concat, const int32_t* self_index,
+                       const float* weight, int64_t ldw, int32_t out_dim, int32_t act,
+                       float* out, int64_t ldo, sage_stream_t stream);
+int sage_layer_forward_supported(int32_t dim, int32_t out_dim, int32_t concat);
+
+/* ---------------------------------------------------------------------------
+ * Backward of the two operators (autograd of encoders.py:58-62 and
+ * aggregators.py:60-74; the reference gets these from torch autograd through
+ * mm / relu / cat / div).
+ *
+ * sage_linear_act_backward: dZ = grad_out * act'(out);
+ *   grad_weight[out_dim, ds+dim] += dZ^T . [self | agg]   (ACCUMULATES: caller zeroes)
+ *   grad_x[n, ds+dim]             = dZ . W                 (written; nullable)
+ * sage_gather_mean_backward: grad_table[row(nbr[r,j]), :] += grad_agg[r, :] / c
+ *   (fp32 atomics, caller zeroes grad_table; same slot_rows / self_row rules
+ *   as the forward).
+ * ------------------------------------------------------------------------- */
+int sage_linear_act_backward(const float* self_tab, int64_t ld_self, const int32_t* self_index,
+                             const float* agg, int64_t ld_agg, int32_t dim,
+                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act,
+                             const float* out, int64_t ldo, const float* grad_out, int64_t ldg,
+                             int32_t n, const int32_t* n_dev,
+                             float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                             sage_stream_t stream);
+int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int32_t dim,
+                              const int32_t* nbr, const int32_t* cnt, int32_t k,
+                              int32_t n, const int32_t* n_dev,
+                              const int32_t* slot_rows, const int32_t* self_row,
+                              float* grad_table, int64_t table_rows, int64_t ld,
+                              sage_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Two-layer forward: model.py:219-222 wiring of two Encoders, i.e. the
+ * "2-hop forward" the headline metric counts.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    /* Each Encoder holds its own adjacency (encoders.py:21); model.py passes the
+     * same dict to both.  Injecting pre-sampled sets (the reference's
+     * num_sample=None switch, aggregators.py:47-48) = pointing a layer at a CSR
+     * whose rows ARE the sampled sets, with k >= the longest row. */
+    const int64_t* rowptr1;     /* [num_nodes+1]  enc1.adj_lists (inner hop)       */
+    const int32_t* col1;
+    const int64_t* rowptr2;     /* [num_nodes+1]  enc2.adj_lists (outer hop)       */
+    const int32_t* col2;
+    int64_t        num_nodes;
+    const float*   table;       /* [num_nodes, d0] raw features (model.py:214-215) */
+    int64_t        table_ld;
+    int32_t        d0;
+    const float*   w1;          /* [h1, d0 or 2*d0]   enc1.weight                  */
+    int32_t        h1;
+    const float*   w2;          /* [h2, h1 or 2*h1]   enc2.weight                  */
+    int32_t        h2;
+    int32_t        k1;          /* enc1.num_sample (inner hop)                     */
+    int32_t        k2;          /* enc2.num_sample (outer hop, on the seeds)       */
+    int32_t        concat;      /* 1: encoder gcn=False (self || agg); 0: gcn=True */
+    int32_t        agg_self_loop;/* aggregator gcn flag (aggregators.py:50-51)     */
+    int32_t        act1, act2;  /* SAGE_ACT_*                                     */
+    int32_t        nan_empty;   /* 1: reference NaN rule for empty sets; 0: zeros  */
+    int32_t        fused;       /* 1: one-launch layers when supported; 0: never   */
+} sage_model_t;
+
+/* Where the intermediates of one forward live inside the caller's workspace
+ * (byte offsets).  Tests and the benchmark's parity gate read the sampled sets
+ * back through this; h1 is what layer 2 consumes. */
+typedef struct {
+    size_t  total_bytes;
+    size_t  counters;     /* int32[8]: [0] |S1| rows, [1] any_nonempty outer, [2] any_nonempty inner */
+    size_t  hash_keys, hash_rows; int32_t hash_capacity;
+    size_t  s1_nodes;     /* int32[max_s1]  layer-1 node ids; concat: rows [0,B) are the seeds */
+    int32_t max_s1;
+    size_t  nbr2, slot2, cnt2, self_slot2;   /* int32 [B,k2] [B,k2] [B] [B]  */
+    size_t  nbr1, cnt1;                      /* int32 [max_s1,k1] [max_s1]   */
+    size_t  agg1;         /* float [max_s1, d0]   (two-launch form only)     */
+    size_t  h1;           /* float [max_s1, h1]                               */
+    size_t  agg2;         /* float [B, h1]        (two-launch form only)     */
+} sage_ws_layout_t;
+
+int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sage_ws_layout_t* layout_host);
+
+/* seeds int32[batch]; out float[batch, h2] (ldo).  Enqueues the whole forward
+ * on `stream`; no host synchronisation.  The sampled sets are a pure function
+ * of (seed, node id, hop tag). */
+int sage_forward2(const sage_model_t* m, void* workspace, size_t workspace_bytes,
+                  const int32_t* seeds, int32_t batch, uint64_t seed,
+                  float* out, int64_t ldo, sage_stream_t stream);
+
+/* Same forward with hipEvent_t markers around its stages, for in-situ kernel timing
+ * (bench.py roofline).  stage_events: 2*SAGE_NUM_STAGES hipEvent_t handles
+ * (begin, end for stage 0..3 = outer sample, inner sample, layer 1, layer 2); NULL
+ * entries are skipped.  Events are recorded on `stream`. */
+#define SAGE_NUM_STAGES 4
+int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes,
+                           const int32_t* seeds, int32_t batch, uint64_t seed,
+                           float* out, int64_t ldo, sage_stream_t stream,
+                           void* const* stage_events);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE355_H */

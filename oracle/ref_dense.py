@@ -55,10 +55,7 @@ def mean_aggregate(nodes, samp_neighs, features, gcn=False):
     """
     if gcn:
         samp_neighs = [set(s) | {int(nodes[i])} for i, s in enumerate(samp_neighs)]
-    frontier = set()
-    for s in samp_neighs:
-        frontier |= s
-    unique_nodes_list = list(frontier)
+    unique_nodes_list = list(set.union(*samp_neighs))   # same expression => same iteration order
     column_of = {n: c for c, n in enumerate(unique_nodes_list)}
     mask = torch.zeros(len(samp_neighs), len(unique_nodes_list))
     rows, cols = [], []

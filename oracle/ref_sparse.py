@@ -26,8 +26,11 @@ def gather_mean(table, nbr, cnt, self_idx=None, nan_empty=True):
     cnt = torch.as_tensor(np.asarray(cnt), dtype=torch.int64)
     n, k = nbr.shape
     valid = torch.arange(k).unsqueeze(0) < cnt.unsqueeze(1)
-    rows = table[nbr.clamp(min=0)] * valid.unsqueeze(-1)
-    total = rows.sum(1)
+    total = torch.empty((n, table.shape[1]), dtype=torch.float64)
+    step = max(1, (1 << 25) // max(1, k * table.shape[1]))        # bound the [rows, k, D] temporary
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        total[a:b] = (table[nbr[a:b].clamp(min=0)] * valid[a:b].unsqueeze(-1)).sum(1)
     denom = cnt.clone()
     if self_idx is not None:
         self_idx = torch.as_tensor(np.asarray(self_idx), dtype=torch.int64)

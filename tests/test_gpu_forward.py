@@ -1,0 +1,203 @@
+"""GPU parity of the 2-hop forward and of the drop-in nn.Modules.
+
+* against the reference's own outputs (tests/golden/*.npz) on identical, injected
+  neighbour sets -- the fixtures' sets become the rows of a CSR and k >= the longest
+  row, which is the reference's num_sample=None switch (aggregators.py:47-48);
+* against the fp64 oracle on the device sampler's own sets, copied back, at sizes up
+  to BASELINE config 3 (B = 4096, fanout 15/25, D0 = 256, H = 128/128).
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_sparse, sampler_ref
+from sage355 import ops
+from sage355.aggregators import MeanAggregator
+from sage355.encoders import Encoder
+from sage355.engine import TwoHopEngine
+from sage355.graph import CSRGraph, rmat_graph
+from util import TWO_LAYER_CASES, assert_close_rowmax, full_table, load_golden, sets_from_padded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def csr_of_sets(nodes, nbr, cnt, num_nodes):
+    rowptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    deg = np.zeros(num_nodes, dtype=np.int64)
+    deg[nodes] = cnt
+    np.cumsum(deg, out=rowptr[1:])
+    col = np.zeros(max(int(rowptr[-1]), 1), dtype=np.int32)
+    for r, v in enumerate(nodes):
+        col[rowptr[v]:rowptr[v] + cnt[r]] = nbr[r, :cnt[r]]
+    return torch.from_numpy(rowptr).to(DEV), torch.from_numpy(col).to(DEV)
+
+
+def engine_from_golden(g, fused):
+    n = int(g["num_nodes"])
+    gcn = bool(g["gcn"])
+    rp1, c1 = csr_of_sets(g["layer1_nodes"], g["nbr1"], g["cnt1"], n)
+    rp2, c2 = csr_of_sets(g["seeds"], g["nbr2"], g["cnt2"], n)
+    act1 = ops.ACT_SIGMOID if int(g["sigmoid1"]) else ops.ACT_RELU
+    act2 = ops.ACT_SIGMOID if int(g["sigmoid2"]) else ops.ACT_RELU
+    return TwoHopEngine(rp1, c1, full_table(g).to(DEV), torch.from_numpy(g["w1"]).to(DEV), torch.from_numpy(g["w2"]).to(DEV),
+                        k1=max(int(g["cnt1"].max()), 1), k2=max(int(g["cnt2"].max()), 1), concat=not gcn, act1=act1, act2=act2,
+                        fused=fused, max_batch=len(g["seeds"]), rowptr_outer=rp2, col_outer=c2)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", TWO_LAYER_CASES)
+def test_two_hop_forward_matches_reference_golden(name, fused):
+    g = load_golden(name)
+    eng = engine_from_golden(g, fused)
+    out = eng.forward(torch.from_numpy(g["seeds"].astype(np.int32)).to(DEV), seed=1)
+    assert_close_rowmax(out.cpu().t(), g["enc2_out"], rows_dim=1, what=f"{name} enc2_out")
+    inter = eng.intermediates()
+    # layer-1 embeddings of the frontier rows == the reference's enc1 output for those ids
+    pos = {int(v): i for i, v in enumerate(g["layer1_nodes"])}
+    s1 = inter["s1_nodes"].cpu().numpy()
+    ref_h1 = torch.from_numpy(g["enc1_out"]).t()[[pos[int(v)] for v in s1]]
+    assert_close_rowmax(inter["h1"].cpu(), ref_h1, what=f"{name} enc1_out on the frontier")
+    first = inter["first_frontier_row"]
+    assert len(set(s1[first:].tolist())) == len(s1) - first
+    valid = np.arange(g["nbr2"].shape[1])[None, :] < g["cnt2"][:, None]
+    assert set(s1[first:].tolist()) == set(g["nbr2"][valid].tolist())
+
+
+def build_modules(g, num_sample1, num_sample2, cuda, adj1, adj2):
+    """model.py:214-222 wiring with this package's classes."""
+    table = full_table(g)
+    gcn = bool(g["gcn"])
+    features = torch.nn.Embedding(*table.shape)
+    features.weight = torch.nn.Parameter(table, requires_grad=False)
+    i1 = "shared" if int(g["sigmoid1"]) else "None"
+    i2 = "shared" if int(g["sigmoid2"]) else "None"
+    agg1 = MeanAggregator(features, cuda=cuda)
+    enc1 = Encoder(features, table.shape[1], g["w1"].shape[0], adj1, agg1, num_sample=num_sample1, gcn=gcn, cuda=cuda, initializer=i1)
+    agg2 = MeanAggregator(lambda nodes: enc1(nodes).t(), cuda=cuda)
+    enc2 = Encoder(lambda nodes: enc1(nodes).t(), enc1.embed_dim, g["w2"].shape[0], adj2, agg2, num_sample=num_sample2,
+                   base_model=enc1, gcn=gcn, cuda=cuda, initializer=i2)
+    with torch.no_grad():
+        enc1.weight.copy_(torch.from_numpy(g["w1"]))
+        enc2.weight.copy_(torch.from_numpy(g["w2"]))
+    return enc1, enc2
+
+
+@pytest.mark.parametrize("name", TWO_LAYER_CASES)
+def test_modules_strict_path_num_sample_none(name):
+    """Encoder / MeanAggregator used exactly as the reference's own golden run used its classes:
+    pre-sampled dicts, num_sample=None, cuda=False -> CPU tensors [embed_dim, B]."""
+    g = load_golden(name)
+    sets1 = sets_from_padded(g["layer1_nodes"], g["nbr1"], g["cnt1"])
+    sets2 = sets_from_padded(g["seeds"], g["nbr2"], g["cnt2"])
+    enc1, enc2 = build_modules(g, None, None, False, sets1, sets2)
+    seeds = [int(s) for s in g["seeds"]]
+    with torch.no_grad():
+        l1 = [int(x) for x in g["layer1_nodes"]]
+        agg1 = enc1.aggregator.forward(l1, [sets1[u] for u in l1], None)
+        out1 = enc1(torch.LongTensor(l1))
+        out2 = enc2(seeds)
+    assert not out2.is_cuda and out2.shape == g["enc2_out"].shape
+    assert_close_rowmax(agg1, g["agg1_out"], what="agg1_out")
+    assert_close_rowmax(out1, g["enc1_out"], rows_dim=1, what="enc1_out")
+    assert_close_rowmax(out2, g["enc2_out"], rows_dim=1, what="enc2_out")
+
+
+@pytest.mark.parametrize("name", ["tiny_gcn", "cora_emb_gcn_5_5", "cora_emb_concat_10_10", "pubmed_gcn_10_25"])
+def test_modules_fast_path_takes_whole_sets(name):
+    """Same fixtures through the device-sampler path: with num_sample >= every set size the sampler's
+    take-all branch reproduces the injected sets, so the fused 2-hop engine must hit the golden too."""
+    g = load_golden(name)
+    sets1 = sets_from_padded(g["layer1_nodes"], g["nbr1"], g["cnt1"])
+    sets2 = sets_from_padded(g["seeds"], g["nbr2"], g["cnt2"])
+    enc1, enc2 = build_modules(g, int(g["k1"]), int(g["k2"]), True, sets1, sets2)
+    assert enc2._can_fuse_two_hop()
+    with torch.no_grad():
+        out2 = enc2(g["seeds"])                     # numpy ids, as model.py:256 passes `val`
+    assert out2.is_cuda
+    assert_close_rowmax(out2.cpu(), g["enc2_out"], rows_dim=1, what="enc2_out (fast path)")
+
+
+def test_strict_path_consumes_python_random_like_the_reference():
+    """sampler_stream.npz: the reference ran with ITS sampler on after random.seed(2024).  The
+    generic module path samples with the same calls on the same stream, so it must land on the
+    same output (aggregators.py:42-46)."""
+    g = load_golden("sampler_stream")
+    graph = CSRGraph(g["rowptr"], g["col"], len(g["rowptr"]) - 1)
+    adj = graph.to_adj_lists()
+    table = torch.from_numpy(g["table"])
+    features = torch.nn.Embedding(*table.shape)
+    features.weight = torch.nn.Parameter(table, requires_grad=False)
+    agg1 = MeanAggregator(features)
+    enc1 = Encoder(features, table.shape[1], 16, adj, agg1, num_sample=int(g["k1"]), gcn=True, fuse_base_model=False)
+    enc1._is_table = lambda: False               # force the reference call sequence at layer 1 too
+    agg2 = MeanAggregator(lambda nodes: enc1(nodes).t())
+    enc2 = Encoder(lambda nodes: enc1(nodes).t(), 16, 8, adj, agg2, num_sample=int(g["k2"]), base_model=enc1, gcn=True,
+                   fuse_base_model=False)
+    with torch.no_grad():
+        enc1.weight.copy_(torch.from_numpy(g["w1"]))
+        enc2.weight.copy_(torch.from_numpy(g["w2"]))
+        random.seed(int(g["py_seed"]))
+        out = enc2([int(s) for s in g["seeds"]])
+    assert_close_rowmax(out, g["enc2_out"], rows_dim=1, what="strict path with live sampling")
+
+
+# ---------------------------------------------------------------- device-sampled sets vs the fp64 oracle
+def check_engine_against_oracle(graph, table, w1, w2, seeds, k1, k2, concat, self_loop, fused, seed=1234):
+    rowptr, col = torch.from_numpy(graph.rowptr).to(DEV), torch.from_numpy(graph.col).to(DEV)
+    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), k1, k2, concat=concat, agg_self_loop=self_loop,
+                       fused=fused, max_batch=len(seeds))
+    out = eng.forward(torch.from_numpy(seeds.astype(np.int32)).to(DEV), seed=seed).cpu()
+    it = eng.intermediates()
+    s1 = it["s1_nodes"].cpu().numpy()
+    nbr2, cnt2 = it["nbr2"].cpu().numpy(), it["cnt2"].cpu().numpy()
+    nbr1, cnt1 = it["nbr1"].cpu().numpy(), it["cnt1"].cpu().numpy()
+    first = it["first_frontier_row"]
+    # integer work, bit exact: the sampled lists are what the C restatement draws for these ids
+    r2, c2 = sampler_ref.sample_neighbors(graph.rowptr, graph.col, seeds, k2, seed, ops.TAG_OUTER)
+    assert np.array_equal(nbr2, r2) and np.array_equal(cnt2, c2)
+    r1, c1 = sampler_ref.sample_neighbors(graph.rowptr, graph.col, s1[first:], k1, seed, ops.TAG_INNER)
+    assert np.array_equal(nbr1[first:], r1) and np.array_equal(cnt1[first:], c1)
+    if concat:
+        assert np.array_equal(s1[:first], seeds)
+        rs, cs = sampler_ref.sample_neighbors(graph.rowptr, graph.col, seeds, k1, seed, ops.TAG_INNER_SELF)
+        assert np.array_equal(nbr1[:first], rs) and np.array_equal(cnt1[:first], cs)
+    valid2 = np.arange(k2)[None, :] < cnt2[:, None]
+    expect = set(nbr2[valid2].tolist()) | (set(seeds.tolist()) if self_loop else set())
+    assert set(s1[first:].tolist()) == expect and len(s1) - first == len(expect)
+    # floating point: fp64 oracle on the very same sets
+    ref = ref_sparse.two_hop_forward(table, w1, w2, seeds, nbr2, cnt2, s1[first:], nbr1[first:], cnt1[first:], gcn=not concat,
+                                     agg_gcn=self_loop, seed_nbr1=nbr1[:first] if concat else None,
+                                     seed_cnt1=cnt1[:first] if concat else None)
+    return assert_close_rowmax(out, ref, what=f"2-hop concat={concat} self_loop={self_loop} fused={fused}")
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("concat,self_loop", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_hop_small_rmat_all_variants(concat, self_loop, fused):
+    graph = rmat_graph(14, 300_000, seed=2)
+    gen = torch.Generator().manual_seed(0)
+    d0, h1, h2 = 100, 64, 32
+    table = torch.randn(graph.num_nodes, d0, generator=gen)
+    m = 2 if concat else 1
+    w1 = torch.randn(h1, m * d0, generator=gen) / np.sqrt(m * d0)
+    w2 = torch.randn(h2, m * h1, generator=gen) / np.sqrt(m * h1)
+    deg = graph.degrees()
+    seeds = np.random.default_rng(1).choice(np.nonzero(deg > 0)[0], 777, replace=False)
+    check_engine_against_oracle(graph, table, w1, w2, seeds, 10, 20, concat, self_loop, fused)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_hop_baseline_config3_shape(fused):
+    """BASELINE.json configs[2]: R-MAT 2^20 nodes / 16 M edges, D0 = 256, H = 128/128, fanout 15/25, B = 4096."""
+    graph = rmat_graph(20, 16_000_000, seed=0, cache_dir="/tmp/sage_cache")
+    gen = torch.Generator().manual_seed(0)
+    table = torch.randn(graph.num_nodes, 256, generator=gen)
+    w1 = (torch.rand(128, 256, generator=gen) * 2 - 1) * np.sqrt(6.0 / (128 + 256))
+    w2 = (torch.rand(128, 128, generator=gen) * 2 - 1) * np.sqrt(6.0 / (128 + 128))
+    deg = graph.degrees()
+    seeds = np.random.default_rng(1).choice(np.nonzero(deg > 0)[0], 4096, replace=False)
+    err = check_engine_against_oracle(graph, table, w1, w2, seeds, 15, 25, False, False, fused)
+    print(f"config-3 batch: max |gpu-oracle| / rowmax = {err:.2e}")
