@@ -75,6 +75,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SageError(f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` "
                         "(or __graft_entry__.build()); sage355 has no non-HIP path")
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be in the process
+    # BEFORE libsage355 is mapped, so that the loader resolves our NEEDED libamdhip64.so.7 to that
+    # one runtime: two HIP runtimes in a process do not share streams or allocations.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.sage_abi_version.restype = c_int32
     L.sage_last_error.restype = c_char_p
