@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--mode", choices=["gcn", "concat"], default="gcn",
                     help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")
     ap.add_argument("--unfused", action="store_true", help="two-launch layers (gather_mean + linear_act)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every forward from the host instead of replaying a hipGraph")
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--dim", type=int, default=256)
@@ -154,14 +155,26 @@ def main():
         if not parity_err <= 1e-5:
             raise SystemExit(f"parity gate failed: max |gpu-oracle|/rowmax = {parity_err:.3e}")
 
+    # hipGraph replay: stream s owns steps s, s+S, s+2S, ... as a device-side queue of batch descriptors, so one
+    # graph launch per step is ALL the host does inside the timed region
+    use_graph = not args.no_graph
+    if use_graph:
+        for s in range(nstreams):
+            engines[s].set_queue(seeds_dev[s::nstreams].contiguous(), sampler_seed[s::nstreams])
+            with torch.cuda.stream(streams[s]):
+                engines[s].capture(out=outs[s])
+        torch.cuda.synchronize()
+
     def run(step_range, profiled_events=None):
         for i in step_range:
             s = i % nstreams
             with torch.cuda.stream(streams[s]):
-                if profiled_events is None:
-                    engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s])
-                else:
+                if profiled_events is not None:
                     engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s], stage_events=profiled_events[i])
+                elif use_graph:
+                    engines[s].replay()
+                else:
+                    engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s])
 
     def fence():
         torch.cuda.synchronize()
@@ -262,7 +275,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: R-MAT 2^{args.scale} nodes / {args.edges} edges, {d0}-dim fp32 features, "
                                    f"2-layer GraphSAGE-mean {args.mode} encoder H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU",
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
-                       "streams_in_flight": nstreams, "fused_layers": not args.unfused,
+                       "streams_in_flight": nstreams, "fused_layers": not args.unfused, "hip_graph_replay": use_graph,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
             "parity_max_err_vs_fp64_oracle": parity_err,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -46,7 +46,7 @@ extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sa
     const int64_t max_s1 = B * m->k2 + B;   // frontier of B*k2 ids + B self rows (concat or self-loop)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    L->counters = take(8 * sizeof(int32_t));
+    L->counters = take(16 * sizeof(int32_t));
     L->hash_capacity = next_pow2(2 * B * (m->k2 + 1));
     L->hash_keys = take((size_t)L->hash_capacity * 4);
     L->hash_rows = take((size_t)L->hash_capacity * 4);
@@ -56,6 +56,8 @@ extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sa
     L->slot2 = take((size_t)B * m->k2 * 4);
     L->cnt2 = take((size_t)B * 4);
     L->self_slot2 = take((size_t)B * 4);
+    L->row2 = take((size_t)B * m->k2 * 4);
+    L->self_row2 = take((size_t)B * 4);
     L->nbr1 = take((size_t)max_s1 * m->k1 * 4);
     L->cnt1 = take((size_t)max_s1 * 4);
     L->agg1 = take((size_t)max_s1 * m->d0 * 4);
@@ -79,12 +81,15 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                   uint64_t seed, float* out, int64_t ldo, sage_stream_t stream, void* const* ev) {
     if (int rc = check_model(m)) return rc;
     SAGE_REQUIRE(m->rowptr1 && m->col1 && m->rowptr2 && m->col2 && m->table && m->w1 && m->w2, "forward2: NULL model array");
-    SAGE_REQUIRE(workspace && seeds && out, "forward2: NULL argument");
+    const bool queued = m->queue != nullptr;
+    SAGE_REQUIRE(!queued || (m->queue_len >= 1 && m->queue_cursor), "forward2: batch queue without length / cursor");
+    SAGE_REQUIRE(workspace && (seeds || queued) && out, "forward2: NULL argument");
     SAGE_REQUIRE(batch >= 1, "forward2: batch = %d", batch);
     SAGE_REQUIRE(ldo >= m->h2, "forward2: ldo = %lld < h2", (long long)ldo);
     SAGE_REQUIRE(sage_aligned(workspace, 256), "forward2: workspace not 256-byte aligned");
+    SAGE_REQUIRE(m->ws_batch == 0 || batch <= m->ws_batch, "forward2: batch %d > ws_batch %d", batch, m->ws_batch);
     sage_ws_layout_t L;
-    if (int rc = sage_forward2_layout(m, batch, &L)) return rc;
+    if (int rc = sage_forward2_layout(m, m->ws_batch ? m->ws_batch : batch, &L)) return rc;
     if (L.total_bytes > workspace_bytes) {
         sage_set_error("forward2: workspace %zu bytes < %zu needed for batch %d", workspace_bytes, L.total_bytes, batch);
         return SAGE_ENOSPACE;
@@ -92,7 +97,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     int32_t* counters = (int32_t*)(ws + L.counters);
-    int32_t* s1_count = counters + 0;
+    int32_t* s1_count = counters + 0;      // frontier rows claimed so far (zero based; rows start at first_row)
     int32_t* any2 = counters + 1;
     int32_t* any1 = counters + 2;
     int32_t* s1_nodes = (int32_t*)(ws + L.s1_nodes);
@@ -100,6 +105,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     int32_t* slot2 = (int32_t*)(ws + L.slot2);
     int32_t* cnt2 = (int32_t*)(ws + L.cnt2);
     int32_t* self_slot2 = (int32_t*)(ws + L.self_slot2);
+    int32_t* row2 = (int32_t*)(ws + L.row2);
+    int32_t* self_row2 = (int32_t*)(ws + L.self_row2);
     int32_t* nbr1 = (int32_t*)(ws + L.nbr1);
     int32_t* cnt1 = (int32_t*)(ws + L.cnt1);
     float* agg1 = (float*)(ws + L.agg1);
@@ -108,62 +115,64 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     const sage_frontier_t fr{(int32_t*)(ws + L.hash_keys), (int32_t*)(ws + L.hash_rows), L.hash_capacity, s1_nodes, s1_count, L.max_s1};
     const int first_row = m->concat ? batch : 0;
     const int self_loop = m->agg_self_loop ? 1 : 0;
+    const sage_model_t* qm = queued ? m : nullptr;
+    const sage_finish_t no_fin{nullptr, nullptr};
+    const sage_finish_t fin{counters, queued ? m->queue_cursor : nullptr};
 
-    if (hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), st) != hipSuccess) { sage_set_error("forward2: memset failed"); return SAGE_ELAUNCH; }
-    if (int rc = sage_frontier_reset(&fr, first_row, st)) return rc;
-    if (m->concat) {
-        if (hipMemcpyAsync(s1_nodes, seeds, (size_t)batch * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            sage_set_error("forward2: seed copy failed");
-            return SAGE_ELAUNCH;
-        }
-    }
-    // outer hop: seeds -> nbr2 (+ frontier)
+    // The workspace is self-cleaning (sage_forward2_init once, then every forward leaves the hash
+    // keys wiped and the counters zero), so a forward is exactly 4 launches (6 with two-launch layers).
+    // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
-                                    cnt2, any2, &fr, self_loop, slot2, self_slot2, st))
+                                    cnt2, any2, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
+                                    nullptr, st))
         return rc;
     SAGE_EV(1);
-    // inner hop: S1 -> nbr1 (raw table rows; no dedupe needed, duplicates are served by L2 / Infinity Cache)
+    // 2. inner hop: S1 -> nbr1 (raw table rows; duplicates are served by L2 / Infinity Cache).  Its spare
+    //    threads turn the outer hop's hash slots into frontier rows and wipe the used keys.
+    const sage_resolve_t resolve{slot2, row2, batch * m->k2, self_loop ? self_slot2 : nullptr, self_row2, batch, fr.rows, fr.keys};
     SAGE_EV(2);
     if (int rc = sage_launch_sample(m->rowptr1, m->col1, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
-                                    SAGE_TAG_INNER_SELF, nbr1, cnt1, any1, nullptr, 0, nullptr, nullptr, st))
+                                    SAGE_TAG_INNER_SELF, nbr1, cnt1, any1, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
+                                    &resolve, st))
         return rc;
     SAGE_EV(3);
     const int32_t* nan1 = m->nan_empty ? any1 : nullptr;
     const int32_t* nan2 = m->nan_empty ? any2 : nullptr;
     const int64_t ldw1 = (int64_t)m->d0 * (m->concat ? 2 : 1);
     const int64_t ldw2 = (int64_t)m->h1 * (m->concat ? 2 : 1);
-    // layer 1 on S1
+    // 3. layer 1 on S1
     SAGE_EV(4);
-    const bool fuse1 = m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat);
+    const bool fuse1 = m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 &&
+                       sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
     if (fuse1) {
         if (int rc = sage_launch_layer_fused(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
                                              self_loop ? s1_nodes : nullptr, nan1, m->concat, s1_nodes, m->w1, ldw1, m->h1, m->act1,
-                                             h1, m->h1, st))
+                                             h1, m->h1, first_row, no_fin, st))
             return rc;
     } else {
         if (int rc = sage_launch_gather_mean(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
-                                             self_loop ? s1_nodes : nullptr, nan1, agg1, m->d0, st))
+                                             self_loop ? s1_nodes : nullptr, nan1, agg1, m->d0, first_row, st))
             return rc;
         if (int rc = sage_launch_linear_act(m->concat ? m->table : nullptr, m->table_ld, s1_nodes, agg1, m->d0, m->d0, m->w1, ldw1,
-                                            m->h1, m->act1, L.max_s1, s1_count, h1, m->h1, st))
+                                            m->h1, m->act1, L.max_s1, s1_count, h1, m->h1, first_row, no_fin, st))
             return rc;
     }
     SAGE_EV(5);
-    // layer 2 on the seeds
+    // 4. layer 2 on the seeds; its last block zeroes the counters and advances the batch queue
     SAGE_EV(6);
-    const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat);
+    const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat) && sage_aligned(m->w2, 16);
     if (fuse2) {
-        if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, slot2, cnt2, m->k2, batch, nullptr, fr.rows,
-                                             self_loop ? self_slot2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
-                                             out, ldo, st))
+        if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, row2, cnt2, m->k2, batch, nullptr, nullptr,
+                                             self_loop ? self_row2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
+                                             out, ldo, 0, fin, st))
             return rc;
     } else {
-        if (int rc = sage_launch_gather_mean(h1, L.max_s1, m->h1, m->h1, slot2, cnt2, m->k2, batch, nullptr, fr.rows,
-                                             self_loop ? self_slot2 : nullptr, nan2, agg2, m->h1, st))
+        if (int rc = sage_launch_gather_mean(h1, L.max_s1, m->h1, m->h1, row2, cnt2, m->k2, batch, nullptr, nullptr,
+                                             self_loop ? self_row2 : nullptr, nan2, agg2, m->h1, 0, st))
             return rc;
         if (int rc = sage_launch_linear_act(m->concat ? h1 : nullptr, m->h1, nullptr, agg2, m->h1, m->h1, m->w2, ldw2, m->h2, m->act2,
-                                            batch, nullptr, out, ldo, st))
+                                            batch, nullptr, out, ldo, 0, fin, st))
             return rc;
     }
     SAGE_EV(7);
@@ -180,4 +189,27 @@ extern "C" int sage_forward2_profiled(const sage_model_t* m, void* workspace, si
                                       int32_t batch, uint64_t seed, float* out, int64_t ldo, sage_stream_t stream,
                                       void* const* stage_events) {
     return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, stream, stage_events);
+}
+
+// Put a fresh (or dirty) workspace into the state every forward leaves behind: counters zero,
+// hash keys empty.  Call once after allocating the workspace (and after an aborted stream).
+extern "C" int sage_forward2_init(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t max_batch,
+                                  sage_stream_t stream) {
+    if (int rc = check_model(m)) return rc;
+    SAGE_REQUIRE(workspace && sage_aligned(workspace, 256), "forward2_init: workspace NULL or not 256-byte aligned");
+    sage_ws_layout_t L;
+    if (int rc = sage_forward2_layout(m, max_batch, &L)) return rc;
+    if (L.total_bytes > workspace_bytes) {
+        sage_set_error("forward2_init: workspace %zu bytes < %zu needed for batch %d", workspace_bytes, L.total_bytes, max_batch);
+        return SAGE_ENOSPACE;
+    }
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    // smaller batches use a prefix of the key array with a smaller power-of-two capacity: wipe the largest
+    if (hipMemsetAsync(ws + L.counters, 0, 16 * sizeof(int32_t), st) != hipSuccess ||
+        hipMemsetAsync(ws + L.hash_keys, 0xFF, (size_t)L.hash_capacity * 4, st) != hipSuccess) {
+        sage_set_error("forward2_init: memset failed");
+        return SAGE_ELAUNCH;
+    }
+    return SAGE_OK;
 }

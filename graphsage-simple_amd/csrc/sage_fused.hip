@@ -1,17 +1,264 @@
-// One-launch GraphSAGE layer: gather-mean tile in LDS -> fp32 MFMA -> act.
-// (first milestone: dispatch only; kernels follow)
+// One-launch GraphSAGE layer: sample lists -> gather-mean tile in LDS -> fp32 MFMA -> act.
+//
+// Replaces one whole Encoder.forward after sampling (aggregators.py:52-74 + encoders.py:49-62)
+// without the [n, dim] aggregate ever leaving the CU.  Structure (256 threads = 4 waves):
+//
+//   phase A  each wave gathers M/4 destination rows: lane l owns columns 4l..4l+3 (one
+//            global_load_dwordx4 = one 1 KiB row per wave-instruction at dim = 256), neighbour
+//            ids broadcast by v_readlane, 8 rows in flight per wave; the mean (and, for the
+//            concat encoder, the node's own row) is written to an fp32 LDS tile
+//            A[chunk][M][KP+4]   (+4 floats = one ds_read_b128 width: conflict-free operand reads)
+//   phase B  wave w owns output columns [32w, 32w+32).  Its slice of W ([32, KP] fp32) lives in
+//            VGPRs for the whole kernel (persistent blocks, loaded once when the layer has a
+//            single K chunk), so the MFMA loop reads only A from LDS: per 8-deep k-step one
+//            ds_read_b128 per 32-row block feeds 4 v_mfma_f32_32x32x2_f32.
+//            Lane (i = l&31, h = l>>5) supplies A[i][8q+4h+t] and W[n0+i][8q+4h+t] to MFMA 4q+t:
+//            any k-pairing is valid as long as A and B agree, and this one makes both operands
+//            16-byte contiguous per lane.
+//   epilogue act() and store out[row, n0 + (l&31)] (128-B segments per accumulator register).
+//
+// HBM-bound: the gather moves ~14 KiB per destination row against 65 kFLOP of MFMA work, so the
+// matrix pipe is idle most of the time; two blocks per CU (LDS 66.5 KiB each at M=64, KP=256;
+// <= 256 VGPRs) let one block's MFMA phase hide under the other's gather.
+#include <stdlib.h>
+
 #include "sage_internal.h"
 
-bool sage_layer_fused_supported(int32_t dim, int32_t out_dim, int32_t concat) {
-    (void)dim; (void)out_dim; (void)concat;
-    return false;
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct FusedArgs {
+    const float* table; int table_rows; int64_t ld; int dim;
+    const int32_t* nbr; const int32_t* cnt; int k; int n; const int32_t* n_dev;
+    const int32_t* slot_rows; const int32_t* self_row; const int32_t* any_nonempty;
+    const int32_t* self_index;
+    const float* W; int64_t ldw; int out_dim; int act;
+    float* out; int64_t ldo;
+    int n_off; sage_finish_t fin;
+};
+
+// KP: padded K per chunk; M: rows per tile; WAVES: waves per block (all gather; waves (w&3, w>>2)
+// own output columns [32(w&3), +32) of 32-row block(s) w>>2); WREG: keep the wave's W slice in
+// VGPRs for the whole kernel (big layers) or stream it from L2 inside the MFMA loop (small
+// layers, where 16 waves per block buy gather parallelism and cap the VGPR budget at 128).
+template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
+__global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void layer_fused_kernel(const FusedArgs a) {
+    constexpr int LDA = KP + 4;                 // floats per LDS row
+    constexpr int CHUNKS = CONCAT ? 2 : 1;
+    constexpr int MB = M / 32;                  // 32-row MFMA blocks per tile
+    constexpr int MGROUPS = WAVES / 4;          // wave groups along M
+    constexpr int MBW = (MB + MGROUPS - 1) / MGROUPS;   // 32-row blocks per wave
+    constexpr int RPW = M / WAVES;              // rows gathered per wave
+    static_assert(M % WAVES == 0 && M % 32 == 0 && WAVES % 4 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [CHUNKS][M][LDA]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nn = a.n;
+    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
+    const int ntiles = (nn + M - 1) / M;
+    if ((int)blockIdx.x >= ntiles) {
+        sage_finish_block(a.fin, (int)gridDim.x);
+        return;
+    }
+    const bool nan_rule = a.any_nonempty ? (*a.any_nonempty != 0) : false;
+    const int last_row = a.table_rows - 1;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int n0 = (wave & 3) * 32;
+    const int mb0 = (wave >> 2) * MBW;
+    const bool mfma_wave = n0 < a.out_dim && mb0 < MB;
+    const int c0 = lane * 4;                    // this lane's columns in phase A
+    const bool col_ok = c0 < a.dim;             // dim % 4 == 0 (host-checked)
+    const bool col_pad = c0 < KP;               // columns [dim, KP) are zero padding
+    const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
+    const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
+
+    // ---- W slice -> registers (per K chunk): breg[4q+t] = W[n0+i][chunk*dim + 8q + 4h + t]
+    float breg[WREG ? KP / 2 : 4];
+    auto load_wq = [&](int chunk, int q) {
+        const int kc = 8 * q + 4 * h;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (wrow_ok && kc < a.dim) v = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
+        return v;
+    };
+    auto load_w = [&](int chunk) {
+        if constexpr (WREG) {
+#pragma unroll
+            for (int q = 0; q < KP / 8; ++q) {
+                const f32x4 v = load_wq(chunk, q);
+                breg[4 * q + 0] = v[0]; breg[4 * q + 1] = v[1]; breg[4 * q + 2] = v[2]; breg[4 * q + 3] = v[3];
+            }
+        }
+    };
+    if (CHUNKS == 1) load_w(0);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * M;
+        // ------------------------------------------------------------ phase A: gather-mean -> LDS
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave + WAVES * rr;        // row inside the tile
+            const int g = row0 + r;
+            if (g >= nn) continue;                  // wave-uniform; rows past nn are never stored
+            const int c = __builtin_amdgcn_readfirstlane(a.cnt[g]);
+            int s = -1;
+            if (a.self_row) {
+                s = a.self_row[g];
+                if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+                s = __builtin_amdgcn_readfirstlane(s);
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            bool extra = s >= 0;
+            for (int base = 0; base < c; base += kWave) {
+                const int m = min(kWave, c - base);
+                int myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
+                if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                if (extra && __any(lane < m && myid == s)) extra = false;      // aggregators.py:50-51: set union
+                myid = min(max(myid, 0), last_row);
+                for (int j0 = 0; j0 < m; j0 += INFLIGHT) {
+                    f32x4 t[INFLIGHT];
+#pragma unroll
+                    for (int u = 0; u < INFLIGHT; ++u) {
+                        const int id = __builtin_amdgcn_readlane(myid, min(j0 + u, m - 1));
+                        if (col_ok) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
+                        else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < INFLIGHT; ++u)
+                        if (j0 + u < m) acc += t[u];
+                }
+            }
+            if (extra && col_ok) acc += *reinterpret_cast<const f32x4*>(a.table + (int64_t)min(s, last_row) * a.ld + c0);
+            const int ceff = c + (extra ? 1 : 0);
+            f32x4 mean;
+            if (ceff > 0) mean = acc * (1.0f / (float)ceff);
+            else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
+            if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col_pad) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + r) * LDA + c0) = mean;
+            if (CONCAT) {
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+                if (col_ok) {
+                    const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), last_row) : (int64_t)min(g, last_row);
+                    sv = *reinterpret_cast<const f32x4*>(a.table + sr * a.ld + c0);
+                }
+                if (col_pad) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv;
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ phase B: [M, K] x W^T on the matrix pipe
+        if (mfma_wave) {
+            f32x16 acc[MBW];
+#pragma unroll
+            for (int b = 0; b < MBW; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+#pragma unroll
+            for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+                if (CHUNKS > 1) load_w(chunk);
+                const float* abase = lds + (chunk * M + mb0 * 32 + i32) * LDA + 4 * h;
+#pragma unroll
+                for (int q = 0; q < KP / 8; ++q) {
+                    f32x4 av[MBW];
+#pragma unroll
+                    for (int b = 0; b < MBW; ++b) av[b] = *reinterpret_cast<const f32x4*>(abase + b * 32 * LDA + 8 * q);
+                    f32x4 bv;
+                    if constexpr (WREG) bv = f32x4{breg[4 * q], breg[4 * q + 1], breg[4 * q + 2], breg[4 * q + 3]};
+                    else bv = load_wq(chunk, q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int b = 0; b < MBW; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][t], bv[t], acc[b], 0, 0, 0);
+                }
+            }
+            const int col = n0 + i32;
+            if (col < a.out_dim) {
+#pragma unroll
+                for (int b = 0; b < MBW; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int g = row0 + (mb0 + b) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[b][reg], a.act);
+                    }
+            }
+        }
+        __syncthreads();     // the next tile's gather overwrites the LDS tile
+    }
+    sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-int sage_launch_layer_fused(const float*, int64_t, int64_t, int32_t, const int32_t*, const int32_t*, int32_t, int32_t,
-                            const int32_t*, const int32_t*, const int32_t*, const int32_t*, int32_t, const int32_t*,
-                            const float*, int64_t, int32_t, int32_t, float*, int64_t, hipStream_t) {
-    sage_set_error("layer_forward: no fused kernel for this shape");
-    return SAGE_EUNSUPPORTED;
+template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
+int launch(const FusedArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(CONCAT ? 2 : 1) * M * (KP + 4) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            sage_set_error("layer_forward: cannot reserve %zu bytes of LDS", lds);
+            return SAGE_ELAUNCH;
+        }
+        configured = true;
+    }
+    const int tiles = sage_cdiv(a.n, M);
+    const int per_cu = WAVES >= 16 ? 2 : (WREG ? 2 : 4);
+    const int grid = min(tiles, per_cu * kNumCU);
+    hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    SAGE_CHECK_LAUNCH("layer_fused_kernel");
+    return SAGE_OK;
+}
+
+// Tile shape by layer size: a big layer (>= 2 tiles of 64 rows per CU-slot) amortises a register-
+// resident W slice over persistent blocks; a small one is latency bound, so it gets 32-row tiles
+// and 16 gathering waves per block.
+template <int KP, bool CONCAT>
+int launch_by_rows(const FusedArgs& a, hipStream_t st) {
+    constexpr bool kWide = CONCAT && KP == 256;           // two 256-wide chunks: 32-row tiles to fit LDS
+    if (a.n >= 8192) {
+        if constexpr (kWide) return launch<KP, 32, 4, true, CONCAT>(a, st);
+        else {
+            static const int variant = getenv("SAGE_FUSED_VARIANT") ? atoi(getenv("SAGE_FUSED_VARIANT")) : 0;   // experiment switch
+            if (variant == 1) return launch<KP, 64, 4, true, CONCAT, 16>(a, st);
+            if (variant == 2) return launch<KP, 32, 4, false, CONCAT, 8>(a, st);
+            if (variant == 3) return launch<KP, 32, 4, false, CONCAT, 16>(a, st);
+            if (variant == 4) return launch<KP, 32, 4, true, CONCAT, 8>(a, st);
+            if (variant == 5) return launch<KP, 32, 8, false, CONCAT, 8>(a, st);
+            return launch<KP, 64, 4, true, CONCAT>(a, st);
+        }
+    }
+    return launch<KP, 32, 16, false, CONCAT>(a, st);
+}
+
+}  // namespace
+
+bool sage_layer_fused_supported(int32_t dim, int32_t out_dim, int32_t concat) {
+    (void)concat;
+    return dim >= 4 && dim <= 256 && dim % 4 == 0 && out_dim >= 1 && out_dim <= 128;
+}
+
+int sage_launch_layer_fused(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
+                            const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
+                            const int32_t* self_row, const int32_t* any_nonempty, int32_t concat, const int32_t* self_index,
+                            const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo,
+                            int32_t n_off, sage_finish_t fin, hipStream_t st) {
+    if (!sage_layer_fused_supported(dim, out_dim, concat) || ld % 4 != 0 || ldw % 4 != 0 || !sage_aligned(table, 16) ||
+        !sage_aligned(weight, 16)) {
+        sage_set_error("layer_forward: no fused kernel for dim=%d out_dim=%d ld=%lld (needs dim%%4==0, dim<=256, out_dim<=128, 16-B rows)",
+                       dim, out_dim, (long long)ld);
+        return SAGE_EUNSUPPORTED;
+    }
+    if (n == 0) return SAGE_OK;
+    const FusedArgs a{table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, self_index,
+                      weight, ldw, out_dim, act, out, ldo, n_off, fin};
+    const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+    if (!concat) {
+        if (kp == 64) return launch_by_rows<64, false>(a, st);
+        if (kp == 128) return launch_by_rows<128, false>(a, st);
+        return launch_by_rows<256, false>(a, st);
+    }
+    if (kp == 64) return launch_by_rows<64, true>(a, st);
+    if (kp == 128) return launch_by_rows<128, true>(a, st);
+    return launch_by_rows<256, true>(a, st);
 }
 
 extern "C" int sage_layer_forward_supported(int32_t dim, int32_t out_dim, int32_t concat) {
@@ -29,5 +276,6 @@ extern "C" int sage_layer_forward(const float* table, int64_t table_rows, int64_
     SAGE_REQUIRE(table_rows >= 1 && table_rows < (1ll << 31), "layer_forward: table_rows = %lld", (long long)table_rows);
     SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "layer_forward: act = %d", act);
     return sage_launch_layer_fused(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, concat,
-                                   self_index, weight, ldw, out_dim, act, out, ldo, (hipStream_t)stream);
+                                   self_index, weight, ldw, out_dim, act, out, ldo, 0, sage_finish_t{nullptr, nullptr},
+                                   (hipStream_t)stream);
 }

@@ -7,7 +7,7 @@
 // owns 4 consecutive columns (16-B loads, 1 KiB per wave-instruction = one 256-float
 // row), neighbour ids are broadcast from a VGPR with v_readlane so every row address
 // is scalar; the j-loop is unrolled so 8 row loads are in flight per wave.
-#include "sage_common.h"
+#include "sage_internal.h"
 
 namespace {
 
@@ -27,10 +27,10 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo) {
+    float* __restrict__ out, int64_t ldo, int n_off) {
     using V = typename VecT<VEC>::type;
     int nn = n;
-    if (n_dev) nn = min(*n_dev, n);
+    if (n_dev) nn = min(*n_dev + n_off, n);
     const int lane = sage_lane();
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -96,16 +96,17 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(
 
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
-                            const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, hipStream_t st) {
+                            const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
+                            hipStream_t st) {
     if (n == 0) return SAGE_OK;
     const int blocks = min(sage_cdiv(n, 4), kNumCU * 8);
     const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
     if (vec4)
         hipLaunchKernelGGL(gather_mean_kernel<4>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n,
-                           n_dev, slot_rows, self_row, any_nonempty, out, ldo);
+                           n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off);
     else
         hipLaunchKernelGGL(gather_mean_kernel<1>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n,
-                           n_dev, slot_rows, self_row, any_nonempty, out, ldo);
+                           n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off);
     SAGE_CHECK_LAUNCH("gather_mean_kernel");
     return SAGE_OK;
 }
@@ -118,6 +119,6 @@ extern "C" int sage_gather_mean(const float* table, int64_t table_rows, int64_t 
     SAGE_REQUIRE(n >= 0 && k >= 1, "gather_mean: n = %d, k = %d", n, k);
     SAGE_REQUIRE(dim >= 1 && ld >= dim && ldo >= dim, "gather_mean: dim = %d, ld = %lld, ldo = %lld", dim, (long long)ld, (long long)ldo);
     SAGE_REQUIRE(table_rows >= 1 && table_rows < (1ll << 31), "gather_mean: table_rows = %lld", (long long)table_rows);
-    return sage_launch_gather_mean(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo,
+    return sage_launch_gather_mean(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, 0,
                                    (hipStream_t)stream);
 }

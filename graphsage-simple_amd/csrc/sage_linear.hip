@@ -10,7 +10,7 @@
 // LDS.  Wave w owns output columns [32w, 32w+32) and two 32x32 accumulators (rows 0-31,
 // 32-63).  LDS rows are padded to 33 floats: the MFMA operand read is ds_read_b32 with
 // lanes 0-31 on 32 different rows at one k, so stride 33 puts them on 32 distinct banks.
-#include "sage_common.h"
+#include "sage_internal.h"
 
 namespace {
 
@@ -22,14 +22,17 @@ __global__ __launch_bounds__(256) void linear_act_kernel(
     const float* __restrict__ self_tab, int64_t ld_self, const int32_t* __restrict__ self_index,
     const float* __restrict__ agg, int64_t ld_agg, int dim,
     const float* __restrict__ W, int64_t ldw, int out_dim, int act,
-    int n, const int32_t* __restrict__ n_dev, float* __restrict__ out, int64_t ldo) {
+    int n, const int32_t* __restrict__ n_dev, float* __restrict__ out, int64_t ldo, int n_off, sage_finish_t fin) {
     __shared__ float smem[(BM + BN) * LDP];
     float* As = smem;
     float* Bs = smem + BM * LDP;
     int nn = n;
-    if (n_dev) nn = min(*n_dev, n);
+    if (n_dev) nn = min(*n_dev + n_off, n);
     const int m0 = blockIdx.x * BM;
-    if (m0 >= nn) return;
+    if (m0 >= nn) {
+        sage_finish_block(fin, (int)(gridDim.x * gridDim.y));
+        return;
+    }
     const int nb0 = blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ds = self_tab ? dim : 0;
@@ -89,17 +92,18 @@ __global__ __launch_bounds__(256) void linear_act_kernel(
             }
         }
     }
+    sage_finish_block(fin, (int)(gridDim.x * gridDim.y));
 }
 
 }  // namespace
 
 int sage_launch_linear_act(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg, int64_t ld_agg,
                            int32_t dim, const float* weight, int64_t ldw, int32_t out_dim, int32_t act, int32_t n,
-                           const int32_t* n_dev, float* out, int64_t ldo, hipStream_t st) {
+                           const int32_t* n_dev, float* out, int64_t ldo, int32_t n_off, sage_finish_t fin, hipStream_t st) {
     if (n == 0) return SAGE_OK;
     dim3 grid(sage_cdiv(n, BM), sage_cdiv(out_dim, BN));
     hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), 0, st, self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw,
-                       out_dim, act, n, n_dev, out, ldo);
+                       out_dim, act, n, n_dev, out, ldo, n_off, fin);
     SAGE_CHECK_LAUNCH("linear_act_kernel");
     return SAGE_OK;
 }
@@ -113,6 +117,6 @@ extern "C" int sage_linear_act(const float* self_tab, int64_t ld_self, const int
     SAGE_REQUIRE(!self_tab || ld_self >= dim, "linear_act: ld_self = %lld < dim", (long long)ld_self);
     SAGE_REQUIRE(ldw >= (self_tab ? 2 : 1) * (int64_t)dim, "linear_act: ldw = %lld too small", (long long)ldw);
     SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "linear_act: act = %d", act);
-    return sage_launch_linear_act(self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw, out_dim, act, n, n_dev, out, ldo,
-                                  (hipStream_t)stream);
+    return sage_launch_linear_act(self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw, out_dim, act, n, n_dev, out, ldo, 0,
+                                  sage_finish_t{nullptr, nullptr}, (hipStream_t)stream);
 }

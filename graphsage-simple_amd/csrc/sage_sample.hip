@@ -6,18 +6,29 @@
 //   aggregators.py:52-53    unique_nodes_list / unique_nodes (frontier + id->row)
 //
 // Shape of the work: tiny and latency bound (B*k2 = 1e5 ids, |S1|*k1 = 3.5e5 ids at
-// BASELINE config 3) -- integer work, three dependent HBM round trips per node
-// (rowptr -> col -> hash CAS).  One THREAD per node keeps all 64 lanes of a wave busy
-// on different nodes (a wave-per-node Floyd loop would idle 63 lanes in its sequential
-// part); the k chosen positions of a thread live in LDS, laid out [slot][thread] so a
-// wave's accesses hit 64 distinct banks.  Frontier rows are reserved per BLOCK (one
-// global atomic per 128 nodes): a single counter word saturates at ~88 atomics/us on
-// this part, so per-thread reservation would cost hundreds of us.
-#include "sage_common.h"
+// BASELINE config 3) -- integer work, a chain of dependent HBM round trips per node
+// (rowptr -> col -> hash CAS).  A GROUP of G = 8/16/32/64 lanes owns one node and lane i
+// owns sample slot i, so every memory step of the chain is one wave-wide instruction
+// (k col reads, k hash CAS in flight at once); a first version with one thread per node
+// serialised its k CAS round trips and took 52 us for 4096 seeds.  Floyd's subset
+// algorithm is inherently sequential in i, but each step only asks "is t_i among the
+// i positions already chosen": one group-wide compare + ballot, so the k steps cost
+// ~8 instructions each for the whole group.  Frontier rows are reserved per BLOCK
+// (wave ballot -> LDS counter -> one global atomic per block): a single counter word
+// saturates at ~88 atomics/us on this part.
+#include "sage_internal.h"
 
 namespace {
 
-constexpr int kThreads = 128;
+// Where a launch takes its node list / sampler key from: the call arguments, or the current
+// descriptor of a device-side batch queue (graph replay).
+struct BatchSrc {
+    const sage_batch_t* queue;
+    const int32_t* cursor;
+    int len;
+    int nodes_from_batch;     // outer hop: nodes = descriptor seeds; inner hop: only the key
+    int32_t* nodes_copy;      // nullable: nodes[r] is also written here (concat: seeds head S1)
+};
 
 struct FrontierDev {
     int32_t* keys;
@@ -26,107 +37,153 @@ struct FrontierDev {
     int32_t* nodes;
     int32_t* count;
     int32_t max_nodes;
+    int32_t row_off;      // rows handed out are row_off + (counter value); forward2 keeps a zero-based counter
 };
 
-// SAMPLE: draw from the CSR row; otherwise ids come from (in_nbr, in_cnt).
-// FRONTIER: also insert the ids into the hash and reserve frontier rows.
-template <bool SAMPLE, bool FRONTIER>
-__global__ __launch_bounds__(kThreads) void sample_kernel(
+// Side job for the inner-hop launch of forward2 (its grid is sized for the worst-case frontier, so
+// most of its threads are idle): turn the outer hop's hash SLOTS into frontier ROWS for layer 2 and
+// wipe the used hash keys, which leaves the table clean for the next forward without a reset pass.
+struct ResolveJob {
+    const int32_t* slots;      // [n_slots] nbr_slot of the outer hop (-1 = padding)
+    int32_t* rows_out;         // [n_slots] frontier row of each slot
+    int n_slots;
+    const int32_t* self_slots; // nullable [n_self]
+    int32_t* self_rows_out;
+    int n_self;
+    const int32_t* hash_rows;
+    int32_t* hash_keys;
+};
+
+__device__ inline uint32_t philox_word(const Philox4& p, int w) {
+    return w == 0 ? p.v[0] : w == 1 ? p.v[1] : w == 2 ? p.v[2] : p.v[3];
+}
+
+// G lanes per node (k <= G).  SAMPLE: draw from the CSR row; otherwise ids come from
+// (in_nbr, in_cnt).  FRONTIER: also insert the ids into the hash and reserve frontier rows.
+template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
+__global__ __launch_bounds__(THREADS) void sample_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ nodes, int n, const int32_t* __restrict__ n_dev,
     int k, uint32_t key0, uint32_t key1, uint32_t tag, int tag_self_rows, uint32_t tag_self,
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ in_cnt,
     int32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int32_t* __restrict__ any_nonempty,
-    FrontierDev f, int insert_self, int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot) {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    constexpr int T = kThreads;
+    FrontierDev f, int insert_self, int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot, BatchSrc bs,
+    int n_off, ResolveJob rj) {
+    __shared__ int blk[2];                 // [0] rows claimed by this block, [1] their base row
+    constexpr int GPB = THREADS / G;
     const int tid = threadIdx.x;
-    const int r = blockIdx.x * T + tid;
+    const int gl = tid & (G - 1);
+    const int lane = tid & (kWave - 1);
+    const int r = blockIdx.x * GPB + tid / G;
+    if (FRONTIER) {
+        if (tid == 0) blk[0] = 0;
+        __syncthreads();
+    }
     int nn = n;
-    if (n_dev) nn = min(*n_dev, n);
-    const bool active = r < nn;
-    int32_t* ids = lds;                       // [k][T]
-    int c = 0;
-    int32_t v = -1;
-    if (active) {
-        if (SAMPLE) {
-            v = nodes[r];
-            const int64_t s = rowptr[v];
-            const int64_t deg = rowptr[v + 1] - s;
-            if (deg <= (int64_t)k) {
-                c = (int)deg;
-                for (int j = 0; j < c; ++j) ids[j * T + tid] = col[s + j];
-            } else {
-                // Floyd: a uniform k-subset of positions [0, deg) in k steps.
-                c = k;
-                const uint32_t base = (uint32_t)(deg - (int64_t)k);
-                const uint32_t t_ = (r < tag_self_rows) ? tag_self : tag;
-                for (int i0 = 0; i0 < k; i0 += 4) {
-                    const Philox4 rnd = philox4x32_10((uint32_t)v, t_, (uint32_t)(i0 >> 2), 0u, key0, key1);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = i0 + q;
-                        if (i < k) {
-                            const uint32_t j = base + (uint32_t)i;
-                            const uint32_t t = sage_bounded(rnd.v[q], j + 1u);
-                            bool dup = false;
-                            for (int m = 0; m < i; ++m) dup |= (ids[m * T + tid] == (int32_t)t);
-                            ids[i * T + tid] = (int32_t)(dup ? j : t);
-                        }
-                    }
-                }
-                for (int i = 0; i < k; ++i) ids[i * T + tid] = col[s + (int64_t)(uint32_t)ids[i * T + tid]];
+    if (n_dev) nn = min(*n_dev + n_off, n);
+    if (rj.slots) {
+        const int stride = (int)(gridDim.x * THREADS);
+        for (int e = (int)(blockIdx.x * THREADS) + tid; e < rj.n_slots; e += stride) {
+            const int sl = rj.slots[e];
+            int row = -1;
+            if (sl >= 0) { row = rj.hash_rows[sl]; rj.hash_keys[sl] = -1; }
+            rj.rows_out[e] = row;
+        }
+        if (rj.self_slots) {
+            for (int e = (int)(blockIdx.x * THREADS) + tid; e < rj.n_self; e += stride) {
+                const int sl = rj.self_slots[e];
+                int row = -1;
+                if (sl >= 0) { row = rj.hash_rows[sl]; rj.hash_keys[sl] = -1; }
+                rj.self_rows_out[e] = row;
             }
-            cnt[r] = c;
-            for (int j = 0; j < k; ++j) nbr[(int64_t)r * k + j] = (j < c) ? ids[j * T + tid] : -1;
-        } else {
+        }
+    }
+    if (bs.queue) {
+        const sage_batch_t b = bs.queue[*bs.cursor % bs.len];
+        key0 = (uint32_t)b.seed;
+        key1 = (uint32_t)(b.seed >> 32);
+        if (bs.nodes_from_batch) nodes = b.seeds;
+    }
+    const bool active = r < nn;
+    int32_t v = -1, id = -1;
+    int c = 0;
+    if (SAMPLE) {
+        int64_t s = 0, deg = 0;
+        if (active) {
+            v = nodes[r];
+            if (bs.nodes_copy && gl == 0) bs.nodes_copy[r] = v;
+            s = rowptr[v];
+            deg = rowptr[v + 1] - s;
+            c = (int)min(deg, (int64_t)k);
+        }
+        const bool floyd = active && deg > (int64_t)k;
+        uint32_t pos = (uint32_t)gl;        // deg <= k: the whole row, in CSR order
+        if (__any(floyd)) {
+            // Floyd: a uniform k-subset of positions [0, deg).  Step i draws t_i in [0, deg-k+i]
+            // and takes it unless one of the i earlier picks already is t_i, then takes deg-k+i.
+            const uint32_t ji = (uint32_t)(deg - (int64_t)k) + (uint32_t)gl;
+            uint32_t ti = 0;
+            if (floyd && gl < k) {
+                const uint32_t t_ = (r < tag_self_rows) ? tag_self : tag;
+                const Philox4 p = philox4x32_10((uint32_t)v, t_, (uint32_t)(gl >> 2), 0u, key0, key1);
+                ti = sage_bounded(philox_word(p, gl & 3), ji + 1u);
+            }
+            uint32_t chosen = ti;
+            for (int i = 1; i < k; ++i) {
+                const uint32_t t = (uint32_t)__shfl((int)ti, i, G);
+                const unsigned long long b = __ballot(floyd && gl < i && chosen == t);
+                const unsigned long long gb = (G == kWave) ? b : ((b >> (lane - gl)) & ((1ull << (G & 63)) - 1ull));
+                if (gl == i) chosen = gb ? ji : ti;
+            }
+            if (floyd) pos = chosen;
+        }
+        if (active) {
+            if (gl < c) id = col[s + (int64_t)pos];
+            if (gl < k) nbr[(int64_t)r * k + gl] = id;
+            if (gl == 0) cnt[r] = c;
+        }
+    } else {
+        if (active) {
             v = nodes ? nodes[r] : -1;
             c = min(in_cnt[r], k);
-            for (int j = 0; j < c; ++j) ids[j * T + tid] = in_nbr[(int64_t)r * k + j];
+            if (gl < c) id = in_nbr[(int64_t)r * k + gl];
         }
     }
     if (any_nonempty) {
-        if (__any(c > 0) && sage_lane() == 0) atomicOr(any_nonempty, 1);
+        // every wave used to atomicOr this one word: 6000 same-address atomics = 67 us (~88/us).
+        // All writers store the same value, so a plain (agent-scope, L1-bypassing) check + store does.
+        if (__any(c > 0) && lane == 0 &&
+            __hip_atomic_load(any_nonempty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(any_nonempty, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (FRONTIER) {
-        int32_t* slots = lds + k * T;          // [k+1][T]
-        int32_t* blk = lds + (2 * k + 1) * T;  // [0] rows claimed by this block, [1] their base row
-        if (tid == 0) blk[0] = 0;
-        __syncthreads();
-        unsigned long long wonmask = 0ull;
-        bool selfwon = false;
-        int nwon = 0;
+        bool won = false, selfwon = false;
+        int slot = -1, sslot = -1;
+        if (active && gl < c) slot = sage_hash_insert(f.keys, f.mask, id, won);
+        if (active && insert_self && gl == 0) sslot = sage_hash_insert(f.keys, f.mask, v, selfwon);
         if (active) {
-            for (int j = 0; j < c; ++j) {
-                bool won;
-                const int slot = sage_hash_insert(f.keys, f.mask, ids[j * T + tid], won);
-                slots[j * T + tid] = slot;
-                nbr_slot[(int64_t)r * k + j] = slot;
-                if (won) { wonmask |= 1ull << j; ++nwon; }
-            }
-            for (int j = c; j < k; ++j) nbr_slot[(int64_t)r * k + j] = -1;
-            if (insert_self) {
-                const int slot = sage_hash_insert(f.keys, f.mask, v, selfwon);
-                slots[k * T + tid] = slot;
-                self_slot[r] = slot;
-                if (selfwon) ++nwon;
-            }
+            if (gl < k) nbr_slot[(int64_t)r * k + gl] = slot;
+            if (insert_self && gl == 0) self_slot[r] = sslot;
         }
-        const int first = nwon ? atomicAdd(&blk[0], nwon) : 0;
+        const unsigned long long wb = __ballot(won), sb = __ballot(selfwon);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int wcount = __popcll(wb) + __popcll(sb);
+        int wbase = 0;
+        if (lane == 0 && wcount) wbase = atomicAdd(&blk[0], wcount);
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
         __syncthreads();
         if (tid == 0) blk[1] = blk[0] ? atomicAdd(f.count, blk[0]) : 0;
         __syncthreads();
-        int row = blk[1] + first;
-        for (int j = 0; j < c; ++j) {
-            if ((wonmask >> j) & 1ull) {
-                if (row < f.max_nodes) f.nodes[row] = ids[j * T + tid];
-                f.rows[slots[j * T + tid]] = row;
-                ++row;
-            }
+        const int base = f.row_off + blk[1] + wbase;
+        if (won) {
+            const int row = base + __popcll(wb & below);
+            if (row < f.max_nodes) f.nodes[row] = id;
+            f.rows[slot] = row;
         }
         if (selfwon) {
+            const int row = base + __popcll(wb) + __popcll(sb & below);
             if (row < f.max_nodes) f.nodes[row] = v;
-            f.rows[slots[k * T + tid]] = row;
+            f.rows[sslot] = row;
         }
     }
 }
@@ -149,6 +206,21 @@ int check_frontier(const sage_frontier_t* f, int64_t inserts) {
     return SAGE_OK;
 }
 
+template <int G, int THREADS, bool SAMPLE, bool FRONTIER, typename... A>
+void launch_one(int n, hipStream_t st, A... args) {
+    hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(sage_cdiv(n, THREADS / G)), dim3(THREADS), 0, st, args...);
+}
+
+template <bool SAMPLE, bool FRONTIER, typename... A>
+void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
+    // frontier variants use 1024-thread blocks: one global counter atomic per 1024/G nodes
+    constexpr int T = FRONTIER ? 1024 : 256;
+    if (k <= 8) launch_one<8, T, SAMPLE, FRONTIER>(n, st, args...);
+    else if (k <= 16) launch_one<16, T, SAMPLE, FRONTIER>(n, st, args...);
+    else if (k <= 32) launch_one<32, T, SAMPLE, FRONTIER>(n, st, args...);
+    else launch_one<64, T, SAMPLE, FRONTIER>(n, st, args...);
+}
+
 }  // namespace
 
 // Internal launcher shared with sage_forward.hip (tag_self_rows: rows [0, tag_self_rows)
@@ -156,23 +228,24 @@ int check_frontier(const sage_frontier_t* f, int64_t inserts) {
 int sage_launch_sample(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t n, const int32_t* n_dev,
                        int32_t k, uint64_t seed, uint32_t tag, int32_t tag_self_rows, uint32_t tag_self,
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
-                       int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, hipStream_t st) {
+                       int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* qm, int nodes_from_batch,
+                       int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off, const sage_resolve_t* resolve, hipStream_t st) {
     if (n == 0) return SAGE_OK;
-    const int blocks = sage_cdiv(n, kThreads);
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const BatchSrc bs{qm ? qm->queue : nullptr, qm ? qm->queue_cursor : nullptr, qm ? qm->queue_len : 0, nodes_from_batch, nodes_copy};
+    ResolveJob rj{};
+    if (resolve) rj = ResolveJob{resolve->slots, resolve->rows_out, resolve->n_slots, resolve->self_slots, resolve->self_rows_out,
+                                 resolve->n_self, resolve->hash_rows, resolve->hash_keys};
     FrontierDev fd{};
+    const int32_t* none = nullptr;
     if (frontier) {
         fd = FrontierDev{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u,
-                         frontier->nodes, frontier->count, frontier->max_nodes};
-        const size_t lds = ((size_t)(2 * k + 1) * kThreads + 2) * sizeof(int32_t);
-        hipLaunchKernelGGL((sample_kernel<true, true>), dim3(blocks), dim3(kThreads), lds, st, rowptr, col, nodes, n, n_dev, k,
-                           k0, k1, tag, tag_self_rows, tag_self, nullptr, nullptr, nbr, cnt, any_nonempty, fd, insert_self,
-                           nbr_slot, self_slot);
+                         frontier->nodes, frontier->count, frontier->max_nodes, frontier_row_off};
+        launch_by_fanout<true, true>(k, n, st, rowptr, col, nodes, n, n_dev, k, k0, k1, tag, tag_self_rows, tag_self, none, none,
+                                     nbr, cnt, any_nonempty, fd, insert_self, nbr_slot, self_slot, bs, n_off, rj);
     } else {
-        const size_t lds = (size_t)k * kThreads * sizeof(int32_t);
-        hipLaunchKernelGGL((sample_kernel<true, false>), dim3(blocks), dim3(kThreads), lds, st, rowptr, col, nodes, n, n_dev, k,
-                           k0, k1, tag, tag_self_rows, tag_self, nullptr, nullptr, nbr, cnt, any_nonempty, fd, 0, nullptr,
-                           nullptr);
+        launch_by_fanout<true, false>(k, n, st, rowptr, col, nodes, n, n_dev, k, k0, k1, tag, tag_self_rows, tag_self, none, none,
+                                      nbr, cnt, any_nonempty, fd, 0, (int32_t*)nullptr, (int32_t*)nullptr, bs, n_off, rj);
     }
     SAGE_CHECK_LAUNCH("sample_kernel");
     return SAGE_OK;
@@ -202,7 +275,7 @@ extern "C" int sage_sample_neighbors(const int64_t* rowptr, const int32_t* col, 
         SAGE_REQUIRE(!insert_self || self_slot, "sample_neighbors: insert_self needs self_slot");
     }
     return sage_launch_sample(rowptr, col, nodes, n, n_dev, k, seed, tag, 0, tag, nbr, cnt, any_nonempty, frontier, insert_self,
-                              nbr_slot, self_slot, (hipStream_t)stream);
+                              nbr_slot, self_slot, nullptr, 0, nullptr, 0, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int32_t k, const int32_t* self_nodes, int32_t n,
@@ -215,11 +288,12 @@ extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int3
     if (int rc = check_frontier(frontier, (int64_t)n * (k + (self_nodes ? 1 : 0)))) return rc;
     if (n == 0) return SAGE_OK;
     const FrontierDev fd{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u,
-                         frontier->nodes, frontier->count, frontier->max_nodes};
-    const size_t lds = ((size_t)(2 * k + 1) * kThreads + 2) * sizeof(int32_t);
-    hipLaunchKernelGGL((sample_kernel<false, true>), dim3(sage_cdiv(n, kThreads)), dim3(kThreads), lds, (hipStream_t)stream,
-                       nullptr, nullptr, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt, nullptr, nullptr, nullptr, fd,
-                       self_nodes ? 1 : 0, nbr_slot, self_slot);
+                         frontier->nodes, frontier->count, frontier->max_nodes, 0};
+    const int64_t* no64 = nullptr;
+    const int32_t* no32 = nullptr;
+    launch_by_fanout<false, true>(k, n, (hipStream_t)stream, no64, no32, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt,
+                                  (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, fd, self_nodes ? 1 : 0, nbr_slot,
+                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr}, 0, ResolveJob{});
     SAGE_CHECK_LAUNCH("frontier_insert_kernel");
     return SAGE_OK;
 }

@@ -46,14 +46,18 @@ class TwoHopEngine:
         self.layout = native.WsLayout()
         self._model_key = None
         self._model_c = None
+        self._model_q = None
+        self._queue = None
+        self._cursor = None
+        self._graph = None
         self._last_batch = 0
         self._reserve(max_batch)
 
-    def _model(self):
+    def _model(self, queued=False):
         w1, w2 = self.w1, self.w2
-        key = (w1.data_ptr(), w2.data_ptr())
+        key = (w1.data_ptr(), w2.data_ptr(), self._queue.data_ptr() if self._queue is not None else 0)
         if self._model_key == key:
-            return self._model_c
+            return self._model_q if queued else self._model_c
         _row_major(w1.detach(), "w1")
         _row_major(w2.detach(), "w2")
         if not (w1.is_contiguous() and w2.is_contiguous()):
@@ -61,17 +65,89 @@ class TwoHopEngine:
         self._model_c = native.Model(
             self.rowptr1.data_ptr(), self.col1.data_ptr(), self.rowptr2.data_ptr(), self.col2.data_ptr(), self.num_nodes,
             self.table.data_ptr(), self.table_ld, self.d0, w1.data_ptr(), self.h1, w2.data_ptr(), self.h2, self.k1, self.k2,
-            int(self.concat), int(self.agg_self_loop), self.act1, self.act2, int(self.nan_empty), int(self.fused))
+            int(self.concat), int(self.agg_self_loop), self.act1, self.act2, int(self.nan_empty), int(self.fused),
+            int(self.max_batch))
+        self._model_q = None
+        if self._queue is not None:
+            self._model_q = native.Model.from_buffer_copy(self._model_c)
+            self._model_q.queue = self._queue.data_ptr()
+            self._model_q.queue_len = self._queue.shape[0]
+            self._model_q.queue_cursor = self._cursor.data_ptr()
         self._model_key = key
-        return self._model_c
+        return self._model_q if queued else self._model_c
+
+    # ---- device-side batch queue + hipGraph replay (no per-batch host work) ----
+    def set_queue(self, seeds, rng_seeds):
+        """seeds: int32 device tensor [S, B] (kept alive by the engine); rng_seeds: S sampler keys.
+        Builds the ring of sage_batch_t descriptors the kernels read (include/sage355.h)."""
+        if not (isinstance(seeds, torch.Tensor) and seeds.is_cuda and seeds.dtype == torch.int32 and seeds.dim() == 2
+                and seeds.is_contiguous()):
+            raise native.SageError("set_queue: seeds must be a contiguous int32 device tensor [S, B]")
+        s, b = seeds.shape
+        if len(rng_seeds) != s:
+            raise native.SageError("set_queue: one sampler key per batch")
+        self._reserve(b)
+        desc = torch.empty((s, 2), dtype=torch.int64)
+        desc[:, 0] = seeds.data_ptr() + torch.arange(s, dtype=torch.int64) * (b * 4)
+        keys = [int(x) & 0xFFFFFFFFFFFFFFFF for x in rng_seeds]
+        desc[:, 1] = torch.tensor([k - (1 << 64) if k >= (1 << 63) else k for k in keys], dtype=torch.int64)
+        self._queue_seeds = seeds
+        self._queue = desc.to(self.device)
+        self._cursor = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._queue_batch = b
+        self._graph = None
+        self._model_key = None
+
+    def forward_queued(self, out):
+        """One forward on the batch at the queue cursor (advances it).  Capturable."""
+        L = native.lib()
+        rc = L.sage_forward2(self._model(queued=True), self.workspace.data_ptr(), self.workspace.numel(), None,
+                             self._queue_batch, 0, out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            native.check(rc, "forward2 (queued)")
+        self._last_batch = self._queue_batch
+        return out
+
+    def capture(self, out=None):
+        """Capture one queued forward into a hipGraph (torch.cuda.CUDAGraph); replay() then runs
+        batch after batch with a single graph launch each."""
+        if self._queue is None:
+            raise native.SageError("capture: call set_queue first")
+        if out is None:
+            out = torch.empty((self._queue_batch, self.h2), dtype=torch.float32, device=self.device)
+        self._graph_out = out
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up outside capture (function attributes, lazy init)
+            self.forward_queued(out)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_queued(out)
+        self._graph = g
+        self._cursor.zero_()
+        torch.cuda.synchronize()
+        return out
+
+    def replay(self):
+        self._graph.replay()
+        return self._graph_out
+
+    def rewind(self, position=0):
+        self._cursor.fill_(int(position))
 
     def _reserve(self, batch):
         if batch <= self.max_batch:
             return
-        lay = native.WsLayout()
-        native.check(native.lib().sage_forward2_layout(self._model(), int(batch), lay), "forward2_layout")
-        self.workspace = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)
         self.max_batch = int(batch)
+        self._model_key = None
+        model = self._model()
+        native.check(native.lib().sage_forward2_layout(model, self.max_batch, self.layout), "forward2_layout")
+        self.workspace = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
+        native.check(native.lib().sage_forward2_init(model, self.workspace.data_ptr(), self.workspace.numel(), self.max_batch,
+                                                     torch.cuda.current_stream().cuda_stream), "forward2_init")
+        self._graph = None
 
     def forward(self, seeds, seed=0, out=None, stage_events=None):
         """seeds: int32 device tensor (or anything as_ids takes) -> out [B, h2] on device.
@@ -103,19 +179,16 @@ class TwoHopEngine:
     def intermediates(self):
         """Sampled sets and layer-1 state of the LAST forward (synchronises)."""
         L, b = self.layout, self._last_batch
-        native.check(native.lib().sage_forward2_layout(self._model(), b, L), "forward2_layout")
         torch.cuda.synchronize()
-        counters = self._view(L.counters, 8, torch.int32).cpu()
-        n1 = int(counters[0])
+        counters = self._view(L.counters, 16, torch.int32).cpu()
         first = b if self.concat else 0
+        n1 = first + int(counters[8])          # [8..15]: the counters as the last forward left them
         s1 = self._view(L.s1_nodes, L.max_s1, torch.int32)[:n1]
-        rows = self._view(L.hash_rows, L.hash_capacity, torch.int32)
-        slot2 = self._view(L.slot2, b * self.k2, torch.int32).view(b, self.k2)
         return {
             "n_s1": n1, "first_frontier_row": first, "s1_nodes": s1,
             "nbr2": self._view(L.nbr2, b * self.k2, torch.int32).view(b, self.k2),
             "cnt2": self._view(L.cnt2, b, torch.int32),
-            "row2": rows[slot2.clamp(min=0).long()].masked_fill(slot2 < 0, -1),
+            "row2": self._view(L.row2, b * self.k2, torch.int32).view(b, self.k2),
             "nbr1": self._view(L.nbr1, L.max_s1 * self.k1, torch.int32).view(L.max_s1, self.k1)[:n1],
             "cnt1": self._view(L.cnt1, L.max_s1, torch.int32)[:n1],
             "h1": self._view(L.h1, L.max_s1 * self.h1, torch.float32).view(L.max_s1, self.h1)[:n1],

@@ -21,7 +21,7 @@ ABI_VERSION = 1
 SYMBOLS = [
     "sage_abi_version", "sage_last_error", "sage_build_arch", "sage_frontier_reset", "sage_sample_neighbors",
     "sage_frontier_insert", "sage_gather_mean", "sage_linear_act", "sage_layer_forward", "sage_layer_forward_supported",
-    "sage_forward2_layout", "sage_forward2", "sage_forward2_profiled",
+    "sage_forward2_layout", "sage_forward2_init", "sage_forward2", "sage_forward2_profiled",
     "sage_linear_act_backward", "sage_gather_mean_backward",
 ]
 
@@ -40,7 +40,12 @@ class Model(Structure):
                 ("num_nodes", c_int64), ("table", c_void_p), ("table_ld", c_int64), ("d0", c_int32),
                 ("w1", c_void_p), ("h1", c_int32), ("w2", c_void_p), ("h2", c_int32),
                 ("k1", c_int32), ("k2", c_int32), ("concat", c_int32), ("agg_self_loop", c_int32),
-                ("act1", c_int32), ("act2", c_int32), ("nan_empty", c_int32), ("fused", c_int32)]
+                ("act1", c_int32), ("act2", c_int32), ("nan_empty", c_int32), ("fused", c_int32), ("ws_batch", c_int32),
+                ("queue", c_void_p), ("queue_len", c_int32), ("queue_cursor", c_void_p)]
+
+
+class Batch(Structure):      # sage_batch_t, lives in device memory (16 bytes)
+    _fields_ = [("seeds", c_void_p), ("seed", c_uint64)]
 
 
 class WsLayout(Structure):
@@ -48,6 +53,7 @@ class WsLayout(Structure):
                 ("hash_keys", c_size_t), ("hash_rows", c_size_t), ("hash_capacity", c_int32),
                 ("s1_nodes", c_size_t), ("max_s1", c_int32),
                 ("nbr2", c_size_t), ("slot2", c_size_t), ("cnt2", c_size_t), ("self_slot2", c_size_t),
+                ("row2", c_size_t), ("self_row2", c_size_t),
                 ("nbr1", c_size_t), ("cnt1", c_size_t),
                 ("agg1", c_size_t), ("h1", c_size_t), ("agg2", c_size_t)]
 
@@ -95,6 +101,7 @@ def lib():
     L.sage_layer_forward.argtypes = [P, I64, I64, I32, P, P, I32, I32, P, P, P, P, I32, P, P, I64, I32, I32, P, I64, P]
     L.sage_layer_forward_supported.argtypes = [I32, I32, I32]
     L.sage_forward2_layout.argtypes = [POINTER(Model), I32, POINTER(WsLayout)]
+    L.sage_forward2_init.argtypes = [POINTER(Model), P, c_size_t, I32, P]
     L.sage_forward2.argtypes = [POINTER(Model), P, c_size_t, P, I32, c_uint64, P, I64, P]
     L.sage_forward2_profiled.argtypes = [POINTER(Model), P, c_size_t, P, I32, c_uint64, P, I64, P, POINTER(c_void_p)]
     L.sage_linear_act_backward.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,

@@ -197,6 +197,16 @@ int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int32_t dim,
  * Two-layer forward: model.py:219-222 wiring of two Encoders, i.e. the
  * "2-hop forward" the headline metric counts.
  * ------------------------------------------------------------------------- */
+/* A batch descriptor in DEVICE memory: which seeds to embed and the sampler key to use.
+ * A ring of them + a device-side cursor lets a captured hipGraph of sage_forward2 be
+ * replayed for batch after batch with NO per-replay host work: every kernel takes its
+ * seeds pointer and key from queue[*cursor % queue_len], and the last node of the
+ * forward advances the cursor. */
+typedef struct {
+    const int32_t* seeds;   /* [batch] device pointer */
+    uint64_t       seed;    /* sampler key for this batch */
+} sage_batch_t;
+
 typedef struct {
     /* Each Encoder holds its own adjacency (encoders.py:21); model.py passes the
      * same dict to both.  Injecting pre-sampled sets (the reference's
@@ -221,6 +231,12 @@ typedef struct {
     int32_t        act1, act2;  /* SAGE_ACT_*                                     */
     int32_t        nan_empty;   /* 1: reference NaN rule for empty sets; 0: zeros  */
     int32_t        fused;       /* 1: one-launch layers when supported; 0: never   */
+    int32_t        ws_batch;    /* batch size the workspace was laid out and initialised for (sage_forward2_init);
+                                   forwards may use any batch <= ws_batch.  0 = the call's own batch.          */
+    /* optional batch queue (all NULL/0 = take `seeds` and `seed` from the call arguments) */
+    const sage_batch_t* queue;  /* [queue_len] descriptors in device memory            */
+    int32_t        queue_len;
+    int32_t*       queue_cursor;/* [1] device counter, advanced by one per forward      */
 } sage_model_t;
 
 /* Where the intermediates of one forward live inside the caller's workspace
@@ -228,11 +244,14 @@ typedef struct {
  * back through this; h1 is what layer 2 consumes. */
 typedef struct {
     size_t  total_bytes;
-    size_t  counters;     /* int32[8]: [0] |S1| rows, [1] any_nonempty outer, [2] any_nonempty inner */
+    size_t  counters;     /* int32[8]: [0] frontier rows claimed (|S1| = first row + this), [1] any_nonempty
+                             outer, [2] any_nonempty inner, [7] completion ticket; all zero between forwards.
+                             int32[8..15]: copy of [0..7] as the LAST forward left them (read-back only)          */
     size_t  hash_keys, hash_rows; int32_t hash_capacity;
     size_t  s1_nodes;     /* int32[max_s1]  layer-1 node ids; concat: rows [0,B) are the seeds */
     int32_t max_s1;
     size_t  nbr2, slot2, cnt2, self_slot2;   /* int32 [B,k2] [B,k2] [B] [B]  */
+    size_t  row2, self_row2;                 /* int32 [B,k2] [B]: frontier ROW of every outer sample */
     size_t  nbr1, cnt1;                      /* int32 [max_s1,k1] [max_s1]   */
     size_t  agg1;         /* float [max_s1, d0]   (two-launch form only)     */
     size_t  h1;           /* float [max_s1, h1]                               */
@@ -241,9 +260,18 @@ typedef struct {
 
 int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sage_ws_layout_t* layout_host);
 
+/* The workspace is self-cleaning: each forward wipes the hash keys it used and its last
+ * kernel zeroes the device counters, so a forward is 4 launches with no memset / reset.
+ * sage_forward2_init puts a freshly allocated workspace into that state (call it once,
+ * with the LARGEST batch the workspace will see, and use one batch size per workspace
+ * thereafter: the layout, hence the key array, depends on it). */
+int sage_forward2_init(const sage_model_t* m, void* workspace, size_t workspace_bytes,
+                       int32_t max_batch, sage_stream_t stream);
+
 /* seeds int32[batch]; out float[batch, h2] (ldo).  Enqueues the whole forward
  * on `stream`; no host synchronisation.  The sampled sets are a pure function
- * of (seed, node id, hop tag). */
+ * of (seed, node id, hop tag).  With m->queue set, `seeds` and `seed` are ignored
+ * (seeds may be NULL) and the call is safe to capture into a hipGraph. */
 int sage_forward2(const sage_model_t* m, void* workspace, size_t workspace_bytes,
                   const int32_t* seeds, int32_t batch, uint64_t seed,
                   float* out, int64_t ldo, sage_stream_t stream);

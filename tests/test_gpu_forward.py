@@ -201,3 +201,32 @@ def test_two_hop_baseline_config3_shape(fused):
     seeds = np.random.default_rng(1).choice(np.nonzero(deg > 0)[0], 4096, replace=False)
     err = check_engine_against_oracle(graph, table, w1, w2, seeds, 15, 25, False, False, fused)
     print(f"config-3 batch: max |gpu-oracle| / rowmax = {err:.2e}")
+
+
+def test_graph_replay_of_queued_batches_equals_direct_calls():
+    """Device-side batch queue + hipGraph replay (what bench.py times) must give, batch for batch,
+    the bits of the host-enqueued forward with the same seeds and sampler key."""
+    graph = rmat_graph(14, 300_000, seed=2)
+    gen = torch.Generator().manual_seed(3)
+    table = torch.randn(graph.num_nodes, 256, generator=gen).to(DEV)
+    w1 = (torch.randn(128, 256, generator=gen) / 16).to(DEV)
+    w2 = (torch.randn(128, 128, generator=gen) / 11).to(DEV)
+    rowptr, col = graph.to(DEV)
+    deg = graph.degrees()
+    rs = np.random.default_rng(5)
+    seeds = torch.from_numpy(np.stack([rs.choice(np.nonzero(deg > 0)[0], 512, replace=False) for _ in range(5)]).astype(np.int32)).to(DEV)
+    keys = [11, 2**63 + 5, 13, 2**64 - 1, 17]
+    for concat in (False, True):
+        m = 2 if concat else 1
+        w1c = w1.repeat(1, m).contiguous()
+        w2c = w2.repeat(1, m).contiguous()
+        direct = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=512)
+        want = [direct.forward(seeds[i], seed=keys[i]).clone() for i in range(5)]
+        eng = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=512)
+        eng.set_queue(seeds, keys)
+        out = eng.capture()
+        for rnd in range(2):                       # second round: the ring wraps around
+            for i in range(5):
+                eng.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(out, want[i]), f"concat={concat} round {rnd} batch {i}"
