@@ -1,16 +1,203 @@
-// Backward kernels of linear_act / gather_mean (training harness).
+// Backward of linear_act / gather_mean (training harness).
+//
+// The reference obtains these from torch autograd through mm / relu / cat / div
+// (model.py:249 loss.backward()).  Here:
+//   dZ      = grad_out * act'(out)                         (fused into the operand loads)
+//   grad_x  = dZ . W                      [n, ds+dim]      fp32 MFMA, reduction over out_dim
+//   grad_W += dZ^T . [self | agg]         [out_dim, ds+dim] fp32 MFMA, reduction over the n rows,
+//                                                          split across blockIdx.z, fp32 atomics
+//   grad_table[row(nbr[r,j])] += grad_agg[r] / c           fp32 atomics (mean backward = scatter)
+// One generic 64x128x32 MFMA tile kernel with functor operands serves both GEMMs; the training
+// layers are small (Cora / Pubmed scale), so operand loads are simple guarded scalar loads.
 #include "sage_internal.h"
 
-extern "C" int sage_linear_act_backward(const float*, int64_t, const int32_t*, const float*, int64_t, int32_t, const float*,
-                                        int64_t, int32_t, int32_t, const float*, int64_t, const float*, int64_t, int32_t,
-                                        const int32_t*, float*, int64_t, float*, int64_t, sage_stream_t) {
-    sage_set_error("linear_act_backward: not built yet");
-    return SAGE_EUNSUPPORTED;
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 64, BN = 128, BK = 32, LDP = BK + 1;
+
+struct Dz {   // dZ(m, h) = grad_out[m, h] * act'(out[m, h])
+    const float* out; int64_t ldo; const float* gout; int64_t ldg; int act;
+    __device__ float operator()(int m, int h) const {
+        const float g = gout[(int64_t)m * ldg + h];
+        const float y = out[(int64_t)m * ldo + h];
+        if (act == SAGE_ACT_RELU) return y > 0.f ? g : 0.f;
+        if (act == SAGE_ACT_SIGMOID) return g * y * (1.f - y);
+        return g;
+    }
+};
+
+struct Xcat {  // X(m, j) = [self | agg](m, j), the forward's operand (encoders.py:49-56)
+    const float* self_tab; int64_t ld_self; const int32_t* self_index; const float* agg; int64_t ld_agg; int ds;
+    __device__ float operator()(int m, int j) const {
+        if (j < ds) {
+            const int64_t sr = self_index ? (int64_t)self_index[m] : (int64_t)m;
+            return self_tab[sr * ld_self + j];
+        }
+        return agg[(int64_t)m * ld_agg + (j - ds)];
+    }
+};
+
+// C[M, N] (+)= sum_k A(m, k) * B(n, k).  MODE 0: A(m,k)=dZ(m,k), B(n,k)=W[k][n]  -> grad_x (store)
+//                                         MODE 1: A(m,k)=dZ(k,m), B(n,k)=X(k,n)  -> grad_W (atomic add, split K)
+template <int MODE>
+__global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const float* __restrict__ W, int64_t ldw,
+                                                       int M, int N, int K, float* __restrict__ C, int64_t ldc, int ksplit) {
+    __shared__ float smem[(BM + BN) * LDP];
+    float* As = smem;
+    float* Bs = smem + BM * LDP;
+    const int m0 = blockIdx.x * BM, nb0 = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kper = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+    if (kbeg >= kend) return;
+    const int wave_n0 = nb0 + wave * 32;
+    const bool wave_active = wave_n0 < N;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int kk = tid & 31, rr = tid >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const int gk = k0 + kk;
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {
+            const int row = rr + 8 * i, gm = m0 + row;
+            float v = 0.f;
+            if (gm < M && gk < kend) v = (MODE == 0) ? dz(gm, gk) : dz(gk, gm);
+            As[row * LDP + kk] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 8; ++i) {
+            const int row = rr + 8 * i, gn = nb0 + row;
+            float v = 0.f;
+            if (gn < N && gk < kend) v = (MODE == 0) ? W[(int64_t)gk * ldw + gn] : x(gk, gn);
+            Bs[row * LDP + kk] = v;
+        }
+        __syncthreads();
+        if (wave_active) {
+            const float* a0p = As + (lane & 31) * LDP + (lane >> 5);
+            const float* a1p = a0p + 32 * LDP;
+            const float* bp = Bs + (wave * 32 + (lane & 31)) * LDP + (lane >> 5);
+#pragma unroll
+            for (int q = 0; q < BK; q += 2) {
+                const float b = bp[q];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[q], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[q], b, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave_active) {
+        const int col = wave_n0 + (lane & 31);
+        if (col < N) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int g0 = m0 + row, g1 = m0 + 32 + row;
+                if (MODE == 0) {
+                    if (g0 < M) C[(int64_t)g0 * ldc + col] = acc0[reg];
+                    if (g1 < M) C[(int64_t)g1 * ldc + col] = acc1[reg];
+                } else {
+                    if (g0 < M) atomicAdd(&C[(int64_t)g0 * ldc + col], acc0[reg]);
+                    if (g1 < M) atomicAdd(&C[(int64_t)g1 * ldc + col], acc1[reg]);
+                }
+            }
+        }
+    }
 }
 
-extern "C" int sage_gather_mean_backward(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int32_t, int32_t,
-                                         const int32_t*, const int32_t*, const int32_t*, float*, int64_t, int64_t,
-                                         sage_stream_t) {
-    sage_set_error("gather_mean_backward: not built yet");
-    return SAGE_EUNSUPPORTED;
+// mean backward: one wave per destination row, lanes over columns
+__global__ __launch_bounds__(256) void gather_mean_bwd_kernel(const float* __restrict__ gagg, int64_t ldg, int dim,
+                                                              const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k,
+                                                              int n, const int32_t* __restrict__ n_dev,
+                                                              const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row,
+                                                              float* __restrict__ gtab, int table_rows, int64_t ld) {
+    int nn = n;
+    if (n_dev) nn = min(*n_dev, n);
+    const int lane = sage_lane();
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int r = wave; r < nn; r += nwaves) {
+        const int c = __builtin_amdgcn_readfirstlane(cnt[r]);
+        int s = -1;
+        if (self_row) {
+            s = self_row[r];
+            if (slot_rows && s >= 0) s = slot_rows[s];
+            s = __builtin_amdgcn_readfirstlane(s);
+        }
+        bool extra = s >= 0;
+        if (extra) {
+            for (int base = 0; base < c; base += kWave) {
+                int id = (base + lane < c) ? nbr[(int64_t)r * k + base + lane] : -1;
+                if (slot_rows && id >= 0) id = slot_rows[id];
+                if (__any(id == s)) extra = false;
+            }
+        }
+        const int ceff = c + (extra ? 1 : 0);
+        if (ceff == 0) continue;
+        const float inv = 1.0f / (float)ceff;
+        for (int j = 0; j < ceff; ++j) {
+            int id;
+            if (j < c) {
+                id = nbr[(int64_t)r * k + j];
+                if (slot_rows) id = slot_rows[max(id, 0)];
+            } else {
+                id = s;
+            }
+            if (id < 0 || id >= table_rows) continue;
+            for (int col = lane; col < dim; col += kWave)
+                atomicAdd(&gtab[(int64_t)id * ld + col], gagg[(int64_t)r * ldg + col] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg,
+                                        int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
+                                        int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
+                                        const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                                        sage_stream_t stream) {
+    SAGE_REQUIRE(agg && weight && out && grad_out, "linear_act_backward: NULL array");
+    SAGE_REQUIRE(n >= 0 && dim >= 1 && out_dim >= 1, "linear_act_backward: n = %d, dim = %d, out_dim = %d", n, dim, out_dim);
+    SAGE_REQUIRE(!n_dev, "linear_act_backward: device-side row counts are not supported");
+    SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "linear_act_backward: act = %d", act);
+    const int ds = self_tab ? dim : 0, K = ds + dim;
+    SAGE_REQUIRE(ld_agg >= dim && ldo >= out_dim && ldg >= out_dim && ldw >= K, "linear_act_backward: leading dimensions");
+    SAGE_REQUIRE(!self_tab || ld_self >= dim, "linear_act_backward: ld_self");
+    SAGE_REQUIRE(!grad_weight || ldgw >= K, "linear_act_backward: ldgw = %lld < %d", (long long)ldgw, K);
+    SAGE_REQUIRE(!grad_x || ldgx >= K, "linear_act_backward: ldgx = %lld < %d", (long long)ldgx, K);
+    if (n == 0) return SAGE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const Dz dz{out, ldo, grad_out, ldg, act};
+    const Xcat x{self_tab, ld_self, self_index, agg, ld_agg, ds};
+    if (grad_x) {
+        dim3 grid(sage_cdiv(n, BM), sage_cdiv(K, BN), 1);
+        hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1);
+        SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_x>");
+    }
+    if (grad_weight) {
+        const int tiles = sage_cdiv(out_dim, BM) * sage_cdiv(K, BN);
+        const int ksplit = max(1, min(sage_cdiv(n, 4 * BK), (2 * kNumCU) / tiles));
+        dim3 grid(sage_cdiv(out_dim, BM), sage_cdiv(K, BN), ksplit);
+        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, grad_weight, ldgw, ksplit);
+        SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_w>");
+    }
+    return SAGE_OK;
+}
+
+extern "C" int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int32_t dim, const int32_t* nbr, const int32_t* cnt,
+                                         int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
+                                         const int32_t* self_row, float* grad_table, int64_t table_rows, int64_t ld,
+                                         sage_stream_t stream) {
+    SAGE_REQUIRE(grad_agg && nbr && cnt && grad_table, "gather_mean_backward: NULL array");
+    SAGE_REQUIRE(n >= 0 && k >= 1 && dim >= 1 && ldg >= dim && ld >= dim, "gather_mean_backward: n=%d k=%d dim=%d", n, k, dim);
+    SAGE_REQUIRE(table_rows >= 1 && table_rows < (1ll << 31), "gather_mean_backward: table_rows = %lld", (long long)table_rows);
+    if (n == 0) return SAGE_OK;
+    const int blocks = min(sage_cdiv(n, 4), kNumCU * 8);
+    hipLaunchKernelGGL(gather_mean_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_agg, ldg, dim, nbr, cnt, k, n, n_dev,
+                       slot_rows, self_row, grad_table, (int)table_rows, ld);
+    SAGE_CHECK_LAUNCH("gather_mean_bwd_kernel");
+    return SAGE_OK;
 }

@@ -20,8 +20,6 @@
 // HBM-bound: the gather moves ~14 KiB per destination row against 65 kFLOP of MFMA work, so the
 // matrix pipe is idle most of the time; two blocks per CU (LDS 66.5 KiB each at M=64, KP=256;
 // <= 256 VGPRs) let one block's MFMA phase hide under the other's gather.
-#include <stdlib.h>
-
 #include "sage_internal.h"
 
 namespace {
@@ -51,6 +49,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     constexpr int MGROUPS = WAVES / 4;          // wave groups along M
     constexpr int MBW = (MB + MGROUPS - 1) / MGROUPS;   // 32-row blocks per wave
     constexpr int RPW = M / WAVES;              // rows gathered per wave
+    constexpr int LG = KP / 4;                  // lanes that cover one row (16-B loads)
+    constexpr int RPP = 64 / LG;                // rows a wave gathers at once
+    constexpr int PASSES = (RPW + RPP - 1) / RPP;
     static_assert(M % WAVES == 0 && M % 32 == 0 && WAVES % 4 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [CHUNKS][M][LDA]
 
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     const int n0 = (wave & 3) * 32;
     const int mb0 = (wave >> 2) * MBW;
     const bool mfma_wave = n0 < a.out_dim && mb0 < MB;
-    const int c0 = lane * 4;                    // this lane's columns in phase A
+    const int lg = lane & (LG - 1), sg = lane / LG;   // lane inside its row group, row group inside the wave
+    const int c0 = lg * 4;                      // this lane's columns in phase A
     const bool col_ok = c0 < a.dim;             // dim % 4 == 0 (host-checked)
     const bool col_pad = c0 < KP;               // columns [dim, KP) are zero padding
     const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
@@ -96,52 +98,109 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * M;
         // ------------------------------------------------------------ phase A: gather-mean -> LDS
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave + WAVES * rr;        // row inside the tile
-            const int g = row0 + r;
-            if (g >= nn) continue;                  // wave-uniform; rows past nn are never stored
-            const int c = __builtin_amdgcn_readfirstlane(a.cnt[g]);
-            int s = -1;
-            if (a.self_row) {
-                s = a.self_row[g];
-                if (a.slot_rows && s >= 0) s = a.slot_rows[s];
-                s = __builtin_amdgcn_readfirstlane(s);
-            }
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            bool extra = s >= 0;
-            for (int base = 0; base < c; base += kWave) {
-                const int m = min(kWave, c - base);
-                int myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
-                if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
-                if (extra && __any(lane < m && myid == s)) extra = false;      // aggregators.py:50-51: set union
-                myid = min(max(myid, 0), last_row);
-                for (int j0 = 0; j0 < m; j0 += INFLIGHT) {
-                    f32x4 t[INFLIGHT];
+        if constexpr (RPP == 1) {
+            // 256-wide rows: the whole wave is on one row, ids are wave-uniform (v_readlane -> scalar address)
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = wave + WAVES * rr;        // row inside the tile
+                const int g = row0 + r;
+                if (g >= nn) continue;                  // wave-uniform; rows past nn are never stored
+                const int c = __builtin_amdgcn_readfirstlane(a.cnt[g]);
+                int s = -1;
+                if (a.self_row) {
+                    s = a.self_row[g];
+                    if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+                    s = __builtin_amdgcn_readfirstlane(s);
+                }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                bool extra = s >= 0;
+                for (int base = 0; base < c; base += kWave) {
+                    const int m = min(kWave, c - base);
+                    int myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
+                    if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                    if (extra && __any(lane < m && myid == s)) extra = false;      // aggregators.py:50-51: set union
+                    myid = min(max(myid, 0), last_row);
+                    for (int j0 = 0; j0 < m; j0 += INFLIGHT) {
+                        f32x4 t[INFLIGHT];
 #pragma unroll
-                    for (int u = 0; u < INFLIGHT; ++u) {
-                        const int id = __builtin_amdgcn_readlane(myid, min(j0 + u, m - 1));
-                        if (col_ok) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
-                        else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int u = 0; u < INFLIGHT; ++u) {
+                            const int id = __builtin_amdgcn_readlane(myid, min(j0 + u, m - 1));
+                            if (col_ok) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
+                            else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                        for (int u = 0; u < INFLIGHT; ++u)
+                            if (j0 + u < m) acc += t[u];
                     }
-#pragma unroll
-                    for (int u = 0; u < INFLIGHT; ++u)
-                        if (j0 + u < m) acc += t[u];
+                }
+                if (extra && col_ok) acc += *reinterpret_cast<const f32x4*>(a.table + (int64_t)min(s, last_row) * a.ld + c0);
+                const int ceff = c + (extra ? 1 : 0);
+                f32x4 mean;
+                if (ceff > 0) mean = acc * (1.0f / (float)ceff);
+                else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
+                if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (col_pad) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + r) * LDA + c0) = mean;
+                if (CONCAT) {
+                    f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+                    if (col_ok) {
+                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), last_row) : (int64_t)min(g, last_row);
+                        sv = *reinterpret_cast<const f32x4*>(a.table + sr * a.ld + c0);
+                    }
+                    if (col_pad) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv;
                 }
             }
-            if (extra && col_ok) acc += *reinterpret_cast<const f32x4*>(a.table + (int64_t)min(s, last_row) * a.ld + c0);
-            const int ceff = c + (extra ? 1 : 0);
-            f32x4 mean;
-            if (ceff > 0) mean = acc * (1.0f / (float)ceff);
-            else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
-            if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (col_pad) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + r) * LDA + c0) = mean;
-            if (CONCAT) {
-                f32x4 sv = {0.f, 0.f, 0.f, 0.f};
-                if (col_ok) {
-                    const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), last_row) : (int64_t)min(g, last_row);
-                    sv = *reinterpret_cast<const f32x4*>(a.table + sr * a.ld + c0);
+        } else {
+            // narrow rows (KP <= 128): LG = KP/4 lanes cover one row, so a wave works on RPP = 64/LG rows at
+            // once -- the dependent chain cnt -> ids -> rows is paid once per pass, not once per row.
+            // Ids are exchanged inside the lane group with a width-LG shuffle.
+            for (int p = 0; p < PASSES; ++p) {
+                const int rsub = p * RPP + sg;               // this lane group's row among the wave's RPW rows
+                const int r = wave * RPW + rsub;
+                const int g = row0 + r;
+                const bool valid = rsub < RPW && g < nn;
+                const int gq = valid ? g : 0;
+                const int c = valid ? a.cnt[gq] : 0;
+                int s = -1;
+                if (valid && a.self_row) {
+                    s = a.self_row[gq];
+                    if (a.slot_rows && s >= 0) s = a.slot_rows[s];
                 }
-                if (col_pad) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                bool extra = s >= 0;
+                for (int base = 0; __any(base < c); base += LG) {
+                    const int m = max(0, min(LG, c - base));
+                    int myid = (lg < m) ? a.nbr[(int64_t)gq * a.k + base + lg] : 0;
+                    if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                    const unsigned long long hit = __ballot(extra && lg < m && myid == s);
+                    if ((hit >> (lane - lg)) & ((1ull << LG) - 1ull)) extra = false;
+                    myid = min(max(myid, 0), last_row);
+                    for (int j0 = 0; __any(j0 < m); j0 += INFLIGHT) {
+                        f32x4 t[INFLIGHT];
+#pragma unroll
+                        for (int u = 0; u < INFLIGHT; ++u) {
+                            const int id = __shfl(myid, max(min(j0 + u, m - 1), 0), LG);
+                            if (col_ok) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
+                            else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                        for (int u = 0; u < INFLIGHT; ++u)
+                            if (j0 + u < m) acc += t[u];
+                    }
+                }
+                if (extra && col_ok) acc += *reinterpret_cast<const f32x4*>(a.table + (int64_t)min(s, last_row) * a.ld + c0);
+                const int ceff = c + (extra ? 1 : 0);
+                f32x4 mean;
+                if (ceff > 0) mean = acc * (1.0f / (float)ceff);
+                else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
+                if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (valid) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + r) * LDA + c0) = mean;
+                if (CONCAT) {
+                    f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+                    if (valid && col_ok) {
+                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[gq], 0), last_row) : (int64_t)min(gq, last_row);
+                        sv = *reinterpret_cast<const f32x4*>(a.table + sr * a.ld + c0);
+                    }
+                    if (valid) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv;
+                }
             }
         }
         __syncthreads();
@@ -201,32 +260,32 @@ int launch(const FusedArgs& a, hipStream_t st) {
         configured = true;
     }
     const int tiles = sage_cdiv(a.n, M);
-    const int per_cu = WAVES >= 16 ? 2 : (WREG ? 2 : 4);
+    const int per_cu = WAVES >= 16 ? 2 : (WAVES == 8 ? 1 : (WREG ? 2 : 4));
     const int grid = min(tiles, per_cu * kNumCU);
     hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     SAGE_CHECK_LAUNCH("layer_fused_kernel");
     return SAGE_OK;
 }
 
-// Tile shape by layer size: a big layer (>= 2 tiles of 64 rows per CU-slot) amortises a register-
-// resident W slice over persistent blocks; a small one is latency bound, so it gets 32-row tiles
-// and 16 gathering waves per block.
+// Tile shape by layer size (measured on MI355X, config-3 layer 1, 23.5k rows x 256 -> 128):
+//   64-row tiles, W slice in VGPRs, 2 blocks/CU ............ 82 us
+//   32-row tiles, W slice in VGPRs, 2 blocks/CU ............ 80 us
+//   32-row tiles, W streamed from L2, 4 blocks/CU (58 VGPR)  77 us   <- big layers
+// The gather is bound by the CU's rate of beyond-L2 row fetches, so neither more loads in flight
+// per wave (8 -> 16) nor more waves moved it; what the last form buys is four blocks per CU whose
+// MFMA phases interleave with the others' gathers.  A small layer (layer 2: 4096 rows) is latency
+// bound instead: 16 gathering waves per 32-row tile, and the W slice preloaded into VGPRs BEFORE
+// the gather so the MFMA loop never waits on L2 (a streamed W cost ~1 us per k-step there).
 template <int KP, bool CONCAT>
 int launch_by_rows(const FusedArgs& a, hipStream_t st) {
     constexpr bool kWide = CONCAT && KP == 256;           // two 256-wide chunks: 32-row tiles to fit LDS
     if (a.n >= 8192) {
         if constexpr (kWide) return launch<KP, 32, 4, true, CONCAT>(a, st);
-        else {
-            static const int variant = getenv("SAGE_FUSED_VARIANT") ? atoi(getenv("SAGE_FUSED_VARIANT")) : 0;   // experiment switch
-            if (variant == 1) return launch<KP, 64, 4, true, CONCAT, 16>(a, st);
-            if (variant == 2) return launch<KP, 32, 4, false, CONCAT, 8>(a, st);
-            if (variant == 3) return launch<KP, 32, 4, false, CONCAT, 16>(a, st);
-            if (variant == 4) return launch<KP, 32, 4, true, CONCAT, 8>(a, st);
-            if (variant == 5) return launch<KP, 32, 8, false, CONCAT, 8>(a, st);
-            return launch<KP, 64, 4, true, CONCAT>(a, st);
-        }
+        else if constexpr (KP == 256) return launch<KP, 32, 4, false, CONCAT>(a, st);
+        else return launch<KP, 64, 4, true, CONCAT>(a, st);
     }
-    return launch<KP, 32, 16, false, CONCAT>(a, st);
+    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, 16, true, CONCAT>(a, st);
+    else return launch<KP, 32, 8, true, CONCAT>(a, st);
 }
 
 }  // namespace

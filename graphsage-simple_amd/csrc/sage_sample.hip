@@ -16,6 +16,8 @@
 // ~8 instructions each for the whole group.  Frontier rows are reserved per BLOCK
 // (wave ballot -> LDS counter -> one global atomic per block): a single counter word
 // saturates at ~88 atomics/us on this part.
+#include <stdlib.h>
+
 #include "sage_internal.h"
 
 namespace {
@@ -211,14 +213,24 @@ void launch_one(int n, hipStream_t st, A... args) {
     hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(sage_cdiv(n, THREADS / G)), dim3(THREADS), 0, st, args...);
 }
 
-template <bool SAMPLE, bool FRONTIER, typename... A>
-void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
-    // frontier variants use 1024-thread blocks: one global counter atomic per 1024/G nodes
-    constexpr int T = FRONTIER ? 1024 : 256;
+template <int T, bool SAMPLE, bool FRONTIER, typename... A>
+void launch_by_fanout_t(int k, int n, hipStream_t st, A... args) {
     if (k <= 8) launch_one<8, T, SAMPLE, FRONTIER>(n, st, args...);
     else if (k <= 16) launch_one<16, T, SAMPLE, FRONTIER>(n, st, args...);
     else if (k <= 32) launch_one<32, T, SAMPLE, FRONTIER>(n, st, args...);
     else launch_one<64, T, SAMPLE, FRONTIER>(n, st, args...);
+}
+
+template <bool SAMPLE, bool FRONTIER, typename... A>
+void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
+    if constexpr (FRONTIER) {
+        static const int t = getenv("SAGE_SO_THREADS") ? atoi(getenv("SAGE_SO_THREADS")) : 1024;   // experiment switch
+        if (t == 256) launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, n, st, args...);
+        else if (t == 512) launch_by_fanout_t<512, SAMPLE, FRONTIER>(k, n, st, args...);
+        else launch_by_fanout_t<1024, SAMPLE, FRONTIER>(k, n, st, args...);
+    } else {
+        launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, n, st, args...);
+    }
 }
 
 }  // namespace
