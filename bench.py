@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SAGE_STREAMS", "4")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SAGE_STREAMS", "2")),
                     help="mini-batches in flight (each on its own HIP stream with its own workspace)")
     ap.add_argument("--mode", choices=["gcn", "concat"], default="gcn",
                     help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")

@@ -196,6 +196,63 @@ def cora_embeddings(names):
     return torch.from_numpy(out)
 
 
+def reference_f1_fixture(g_cora):
+    """Train the REFERENCE model on the stand-in Cora data (real cora.cites topology + synthesised
+    content, sage355/datasets.py), following run_model (model.py:214-259) line for line: seeds,
+    10/10/80 split, SGD lr 0.7, 5 epochs (CLI default), the descending `max` batches of model.py:244,
+    num_sample 10/10 (the reference's effective fanout).  torch is unseeded in the reference
+    (model.py:192-193), so F1 is recorded for five torch seeds."""
+    import json
+    import time
+    from graphsage.model import SupervisedGraphSage
+    from sage355.datasets import standin_citation
+    from sklearn.metrics import f1_score
+    feat_data, labels = standin_citation(g_cora, num_classes=7, feat_dim=1433, seed=0)
+    adj_lists = g_cora.to_adj_lists()
+    runs = []
+    for torch_seed in range(5):
+        torch.manual_seed(torch_seed)
+        np.random.seed(1)
+        random.seed(1)
+        features = torch.nn.Embedding(2708, 1433)
+        features.weight = torch.nn.Parameter(torch.FloatTensor(feat_data), requires_grad=False)
+        agg1 = MeanAggregator(features, cuda=True, feature_dim=100, num_nodes=2708, initializer="None")
+        enc1 = quiet(Encoder, features, 1433, 50, adj_lists, agg1, gcn=True, cuda=False, initializer="None")
+        agg2 = MeanAggregator(lambda nodes: enc1(nodes).t(), 2708, cuda=False)
+        enc2 = quiet(Encoder, lambda nodes: enc1(nodes).t(), enc1.embed_dim, 128, adj_lists, agg2, base_model=enc1, gcn=True, cuda=False)
+        model = SupervisedGraphSage(7, enc2)
+        rand_indices = np.random.permutation(2708)
+        val = rand_indices[270:541]
+        train = list(rand_indices[541:])
+        opt = torch.optim.SGD(filter(lambda p: p.requires_grad, model.parameters()), lr=0.7)
+        times = []
+        for _ in range(5):
+            random.shuffle(train)
+            for batch in range(0, len(train), 128):
+                batch_nodes = train[batch:max(len(train), batch + 128)]
+                t0 = time.time()
+                opt.zero_grad()
+                loss = model.loss(batch_nodes, torch.LongTensor(labels[np.array(batch_nodes)]))
+                loss.backward()
+                opt.step()
+                times.append(time.time() - t0)
+        out = model.forward(val)
+        pred = out.data.numpy().argmax(axis=1)
+        runs.append({"torch_seed": torch_seed, "f1_micro": float(f1_score(labels[val], pred, average="micro")),
+                     "f1_macro": float(f1_score(labels[val], pred, average="macro")), "mean_batch_time": float(np.mean(times))})
+        print("reference F1 run", runs[-1])
+    fixture = {"dataset": "cora.cites topology + sage355.datasets.standin_citation(num_classes=7, feat_dim=1433, seed=0)",
+               "config": {"epochs": 5, "batch_size": 128, "ref_batching": True, "lr": 0.7, "seed": 1, "hidden": [50, 128],
+                          "num_sample": [10, 10], "gcn": True},
+               "runs": runs,
+               "f1_micro_mean": float(np.mean([r["f1_micro"] for r in runs])), "f1_micro_std": float(np.std([r["f1_micro"] for r in runs])),
+               "f1_macro_mean": float(np.mean([r["f1_macro"] for r in runs])), "f1_macro_std": float(np.std([r["f1_macro"] for r in runs]))}
+    with open(os.path.join(HERE, "reference_f1_cora_standin.json"), "w") as fp:
+        json.dump(fixture, fp, indent=1)
+    print("reference F1 micro %.4f +- %.4f, macro %.4f +- %.4f" % (fixture["f1_micro_mean"], fixture["f1_micro_std"],
+                                                                  fixture["f1_macro_mean"], fixture["f1_macro_std"]))
+
+
 def main():
     g_tiny = tiny_graph()
     gen = torch.Generator().manual_seed(0)
@@ -216,9 +273,13 @@ def main():
     two_layer_case("cora_bow_gcn_5_5", g_cora, bow, rs.choice(2708, 32, replace=False), 5, 5, 50, 128, True, 6)
     two_layer_case("cora_bow_concat_5_5", g_cora, bow, rs.choice(2708, 16, replace=False), 5, 5, 50, 128, False, 7)
     sampler_stream_case(g_cora, emb[:, :16].contiguous())
+    np.savez_compressed(os.path.join(HERE, "cora_topology.npz"), rowptr=g_cora.rowptr, col=g_cora.col)
+    if "--f1" in sys.argv or not os.path.exists(os.path.join(HERE, "reference_f1_cora_standin.json")):
+        reference_f1_fixture(g_cora)
 
     g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")
     assert g_pub.num_nodes == 19717, g_pub.num_nodes
+    np.savez_compressed(os.path.join(HERE, "pubmed_topology.npz"), rowptr=g_pub.rowptr, col=g_pub.col)
     tfidf = torch.from_numpy((rs.random((19717, 500)) * (rs.random((19717, 500)) < 0.1)).astype(np.float32))
     two_layer_case("pubmed_gcn_10_25", g_pub, tfidf, rs.choice(19717, 6, replace=False), 10, 25, 50, 128, True, 8)
     two_layer_case("pubmed_concat_10_25", g_pub, tfidf, rs.choice(19717, 4, replace=False), 10, 25, 50, 128, False, 9)
