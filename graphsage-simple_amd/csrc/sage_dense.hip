@@ -1,0 +1,180 @@
+// dense_layer: out = act([self_tab[self_index] | x] . W^T) for an [n, dim] operand that is already in HBM
+// (the column-sliced gather wrote the per-destination means there).  MFMA-bound: 2*n*K*H flop against
+// 4*n*(K+H) bytes is ~40 flop/byte at K = 256, H = 128 (ridge ~20), so unlike the gather this kernel is
+// built around keeping the matrix pipes fed:
+//   * persistent 256-thread blocks; wave w owns output columns [32w, 32w+32) and keeps its W slice
+//     ([32, KP] fp32 = KP/2 VGPRs) in registers for the whole kernel;
+//   * 32-row tiles, double-buffered in LDS; the NEXT tile's rows are requested from HBM/L2 (into VGPRs)
+//     before the MFMA loop of the CURRENT tile starts, so their latency hides under ~4 us of MFMA work;
+//   * one barrier per tile (the double buffer makes the second one unnecessary);
+//   * operands as in sage_fused.hip: lane (i = l&31, h = l>>5) supplies A[i][8q+4h+t] / W[n0+i][8q+4h+t]
+//     to MFMA 4q+t; LDS rows padded by one ds_read_b128 width.
+#include <stdlib.h>
+
+#include "sage_internal.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct DenseArgs {
+    const float* x; int64_t ldx; int dim;
+    int n; const int32_t* n_dev; int n_off;
+    const float* self_tab; int64_t ld_self; int self_rows; const int32_t* self_index;
+    const int32_t* cnt; const int32_t* any_nonempty;    // nullable: rows with cnt == 0 become NaN when *any_nonempty (reference 0/0)
+    const float* W; int64_t ldw; int out_dim; int act;
+    float* out; int64_t ldo;
+    sage_finish_t fin;
+};
+
+template <int KP, bool CONCAT>
+__global__ __launch_bounds__(256, 2) void dense_layer_kernel(const DenseArgs a) {
+    constexpr int M = 32, WAVES = 4;
+    constexpr int LDA = KP + 4;
+    constexpr int CHUNKS = CONCAT ? 2 : 1;
+    constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
+    constexpr int BUF = CHUNKS * M * LDA;                   // floats per LDS buffer
+    static_assert(RPW % RPP == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][CHUNKS][M][LDA]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nn = a.n;
+    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
+    const int ntiles = (nn + M - 1) / M;
+    if ((int)blockIdx.x < ntiles) {
+        const bool nan_rule = (a.cnt && a.any_nonempty) ? (*a.any_nonempty != 0) : false;
+        const int i32 = lane & 31, h = lane >> 5;
+        const int n0 = wave * 32;
+        const bool mfma_wave = n0 < a.out_dim;
+        const int lg = lane & (LG - 1), sg = lane / LG;
+        const int c0 = lg * 4;
+        const bool col_ok = c0 < a.dim;
+        const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
+        const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
+
+        float breg[KP / 2];
+        auto load_w = [&](int chunk) {
+#pragma unroll
+            for (int q = 0; q < KP / 8; ++q) {
+                const int kc = 8 * q + 4 * h;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (wrow_ok && kc < a.dim) v = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
+                breg[4 * q + 0] = v[0]; breg[4 * q + 1] = v[1]; breg[4 * q + 2] = v[2]; breg[4 * q + 3] = v[3];
+            }
+        };
+        if (CHUNKS == 1) load_w(0);
+
+        f32x4 xr[PASSES], sr[CONCAT ? PASSES : 1];
+        auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int g = tile * M + wave * RPW + p * RPP + sg;
+                const bool valid = g < nn && col_ok;
+                xr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (valid) {
+                    xr[p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
+                    if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[p] = f32x4{q, q, q, q}; }
+                }
+                if (CONCAT) {
+                    sr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (valid) {
+                        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1)
+                                                       : (int64_t)min(g, a.self_rows - 1);
+                        sr[p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + c0);
+                    }
+                }
+            }
+        };
+        auto stage_tile = [&](float* buf) {                   // VGPRs -> LDS
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int r = wave * RPW + p * RPP + sg;
+                *reinterpret_cast<f32x4*>(buf + ((CHUNKS - 1) * M + r) * LDA + c0) = xr[p];
+                if (CONCAT) *reinterpret_cast<f32x4*>(buf + r * LDA + c0) = sr[p];
+            }
+        };
+
+        int tile = blockIdx.x, b = 0;
+        request_tile(tile);
+        for (; tile < ntiles; tile += gridDim.x, b ^= 1) {
+            float* buf = lds + b * BUF;
+            stage_tile(buf);
+            __syncthreads();
+            const int next = tile + gridDim.x;
+            if (next < ntiles) request_tile(next);            // in flight during the MFMA loop below
+            if (mfma_wave) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+                    if (CHUNKS > 1) load_w(chunk);
+                    const float* abase = buf + (chunk * M + i32) * LDA + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < KP / 8; ++q) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(abase + 8 * q);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], breg[4 * q + t], acc, 0, 0, 0);
+                    }
+                }
+                const int col = n0 + i32;
+                if (col < a.out_dim) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[reg], a.act);
+                    }
+                }
+            }
+        }
+    }
+    sage_finish_block(a.fin, (int)gridDim.x);
+}
+
+template <int KP, bool CONCAT>
+int launch(const DenseArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (CONCAT ? 2 : 1) * 32 * (KP + 4) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_layer_kernel<KP, CONCAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds) != hipSuccess) {
+            sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
+            return SAGE_ELAUNCH;
+        }
+        configured = true;
+    }
+    static const int per_cu_env = getenv("SAGE_DENSE_BLOCKS") ? atoi(getenv("SAGE_DENSE_BLOCKS")) : 0;   // experiment switch
+    const int per_cu = per_cu_env ? per_cu_env : ((lds > 80 * 1024) ? 1 : 2);
+    const int grid = min(sage_cdiv(a.n, 32), per_cu * kNumCU);
+    hipLaunchKernelGGL((dense_layer_kernel<KP, CONCAT>), dim3(grid), dim3(256), lds, st, a);
+    SAGE_CHECK_LAUNCH("dense_layer_kernel");
+    return SAGE_OK;
+}
+
+}  // namespace
+
+int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n, const int32_t* n_dev, int32_t concat,
+                            const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
+                            const int32_t* cnt, const int32_t* any_nonempty,
+                            const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
+                            sage_finish_t fin, hipStream_t st) {
+    if (!sage_layer_fused_supported(dim, out_dim, concat) || ldx % 4 != 0 || ldw % 4 != 0 || !sage_aligned(x, 16) ||
+        !sage_aligned(weight, 16) || (concat && (ld_self % 4 != 0 || !sage_aligned(self_tab, 16)))) {
+        sage_set_error("layer_dense: unsupported shape dim=%d out_dim=%d", dim, out_dim);
+        return SAGE_EUNSUPPORTED;
+    }
+    if (n == 0) return SAGE_OK;
+    const DenseArgs a{x, ldx, dim, n, n_dev, n_off, concat ? self_tab : x, concat ? ld_self : ldx, concat ? (int)self_rows : n,
+                      self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin};
+    const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+    if (!concat) {
+        if (kp == 64) return launch<64, false>(a, st);
+        if (kp == 128) return launch<128, false>(a, st);
+        return launch<256, false>(a, st);
+    }
+    if (kp == 64) return launch<64, true>(a, st);
+    if (kp == 128) return launch<128, true>(a, st);
+    return launch<256, true>(a, st);
+}

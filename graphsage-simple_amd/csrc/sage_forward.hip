@@ -79,6 +79,7 @@ namespace {
 
 int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                   uint64_t seed, float* out, int64_t ldo, sage_stream_t stream, void* const* ev) {
+    constexpr int SAGE_STAGE_SAMPLE = 1, SAGE_STAGE_GATHER = 2, SAGE_STAGE_OUTPUT = 4, stages = 7;   // kept as structure markers
     if (int rc = check_model(m)) return rc;
     SAGE_REQUIRE(m->rowptr1 && m->col1 && m->rowptr2 && m->col2 && m->table && m->w1 && m->w2, "forward2: NULL model array");
     const bool queued = m->queue != nullptr;
@@ -121,6 +122,16 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
 
     // The workspace is self-cleaning (sage_forward2_init once, then every forward leaves the hash
     // keys wiped and the counters zero), so a forward is exactly 4 launches (6 with two-launch layers).
+    const int64_t ldw1 = (int64_t)m->d0 * (m->concat ? 2 : 1);
+    const int64_t ldw2 = (int64_t)m->h1 * (m->concat ? 2 : 1);
+    const int32_t* nan1 = m->nan_empty ? any1 : nullptr;
+    const int32_t* nan2 = m->nan_empty ? any2 : nullptr;
+    const bool fuse1 = m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 &&
+                       sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
+    // wide + large layer 1: column-sliced gather (cross-XCD L2 partitioning) into agg1, then a dense contraction;
+    // otherwise the one-launch fused layer; otherwise the generic two-launch form
+    const bool split1 = fuse1 && sage_gather_is_sliced(m->d0, m->table_ld, m->d0, m->table, agg1, L.max_s1, m->k1);
+    if (stages & SAGE_STAGE_SAMPLE) {
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
@@ -130,6 +141,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     SAGE_EV(1);
     // 2. inner hop: S1 -> nbr1 (raw table rows; duplicates are served by L2 / Infinity Cache).  Its spare
     //    threads turn the outer hop's hash slots into frontier rows and wipe the used keys.
+    //    (Drawing these samples inside the layer-1 gather instead was measured: the gather went from 48 to
+    //    100 us, its per-row dependent chain growing from 2 to 5 round trips.)
     const sage_resolve_t resolve{slot2, row2, batch * m->k2, self_loop ? self_slot2 : nullptr, self_row2, batch, fr.rows, fr.keys};
     SAGE_EV(2);
     if (int rc = sage_launch_sample(m->rowptr1, m->col1, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
@@ -137,15 +150,25 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                     &resolve, st))
         return rc;
     SAGE_EV(3);
-    const int32_t* nan1 = m->nan_empty ? any1 : nullptr;
-    const int32_t* nan2 = m->nan_empty ? any2 : nullptr;
-    const int64_t ldw1 = (int64_t)m->d0 * (m->concat ? 2 : 1);
-    const int64_t ldw2 = (int64_t)m->h1 * (m->concat ? 2 : 1);
-    // 3. layer 1 on S1
+    }
+    // 3. layer 1 on S1: the HBM-bound gather ...
+    if (stages & SAGE_STAGE_GATHER) {
     SAGE_EV(4);
-    const bool fuse1 = m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 &&
-                       sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
-    if (fuse1) {
+    if (split1) {
+        if (int rc = sage_launch_gather_mean(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
+                                             self_loop ? s1_nodes : nullptr, nan1, agg1, m->d0, first_row, st))
+            return rc;
+    }
+    SAGE_EV(5);
+    }
+    // ... and its contraction (one launch with the gather unless the layer is split); then layer 2
+    if (stages & SAGE_STAGE_OUTPUT) {
+    SAGE_EV(6);
+    if (split1) {
+        if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
+                                             s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, st))
+            return rc;
+    } else if (fuse1) {
         if (int rc = sage_launch_layer_fused(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
                                              self_loop ? s1_nodes : nullptr, nan1, m->concat, s1_nodes, m->w1, ldw1, m->h1, m->act1,
                                              h1, m->h1, first_row, no_fin, st))
@@ -158,9 +181,9 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                             m->h1, m->act1, L.max_s1, s1_count, h1, m->h1, first_row, no_fin, st))
             return rc;
     }
-    SAGE_EV(5);
+    SAGE_EV(7);
     // 4. layer 2 on the seeds; its last block zeroes the counters and advances the batch queue
-    SAGE_EV(6);
+    SAGE_EV(8);
     const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat) && sage_aligned(m->w2, 16);
     if (fuse2) {
         if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, row2, cnt2, m->k2, batch, nullptr, nullptr,
@@ -175,7 +198,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                             batch, nullptr, out, ldo, 0, fin, st))
             return rc;
     }
-    SAGE_EV(7);
+    SAGE_EV(9);
+    }
     return SAGE_OK;
 }
 }  // namespace

@@ -32,6 +32,7 @@ struct FusedArgs {
     const int32_t* nbr; const int32_t* cnt; int k; int n; const int32_t* n_dev;
     const int32_t* slot_rows; const int32_t* self_row; const int32_t* any_nonempty;
     const int32_t* self_index;
+    const float* self_tab; int64_t ld_self; int self_rows;     // concat encoder: where the node's own row comes from
     const float* W; int64_t ldw; int out_dim; int act;
     float* out; int64_t ldo;
     int n_off; sage_finish_t fin;
@@ -41,7 +42,9 @@ struct FusedArgs {
 // own output columns [32(w&3), +32) of 32-row block(s) w>>2); WREG: keep the wave's W slice in
 // VGPRs for the whole kernel (big layers) or stream it from L2 inside the MFMA loop (small
 // layers, where 16 waves per block buy gather parallelism and cap the VGPR budget at 128).
-template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
+// DENSE: `table` already holds one aggregated row per destination (the column-sliced gather wrote it), so
+// phase A is a plain copy of the tile's rows and the kernel is the contraction [n, K] x W^T + act.
+template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8, bool DENSE = false>
 __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void layer_fused_kernel(const FusedArgs a) {
     constexpr int LDA = KP + 4;                 // floats per LDS row
     constexpr int CHUNKS = CONCAT ? 2 : 1;
@@ -98,7 +101,34 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * M;
         // ------------------------------------------------------------ phase A: gather-mean -> LDS
-        if constexpr (RPP == 1) {
+        if constexpr (DENSE) {
+            // every wave copies its RPW rows into the tile; all PASSES wave-instructions are in flight at once
+            f32x4 t[PASSES], sv[CONCAT ? PASSES : 1];
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int rsub = p * RPP + sg;
+                const int g = row0 + wave * RPW + rsub;
+                const bool valid = rsub < RPW && g < nn && col_ok;
+                t[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (valid) t[p] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)g * a.ld + c0);
+                if (CONCAT) {
+                    sv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (valid) {
+                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+                        sv[p] = *reinterpret_cast<const f32x4*>(a.self_tab + sr * a.ld_self + c0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int rsub = p * RPP + sg;
+                const int r = wave * RPW + rsub;
+                if (rsub < RPW && col_pad) {
+                    *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + r) * LDA + c0) = t[p];
+                    if (CONCAT) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv[p];
+                }
+            }
+        } else if constexpr (RPP == 1) {
             // 256-wide rows: the whole wave is on one row, ids are wave-uniform (v_readlane -> scalar address)
             for (int rr = 0; rr < RPW; ++rr) {
                 const int r = wave + WAVES * rr;        // row inside the tile
@@ -142,8 +172,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
                 if (CONCAT) {
                     f32x4 sv = {0.f, 0.f, 0.f, 0.f};
                     if (col_ok) {
-                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), last_row) : (int64_t)min(g, last_row);
-                        sv = *reinterpret_cast<const f32x4*>(a.table + sr * a.ld + c0);
+                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+                        sv = *reinterpret_cast<const f32x4*>(a.self_tab + sr * a.ld_self + c0);
                     }
                     if (col_pad) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv;
                 }
@@ -196,8 +226,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
                 if (CONCAT) {
                     f32x4 sv = {0.f, 0.f, 0.f, 0.f};
                     if (valid && col_ok) {
-                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[gq], 0), last_row) : (int64_t)min(gq, last_row);
-                        sv = *reinterpret_cast<const f32x4*>(a.table + sr * a.ld + c0);
+                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[gq], 0), a.self_rows - 1) : (int64_t)min(gq, a.self_rows - 1);
+                        sv = *reinterpret_cast<const f32x4*>(a.self_tab + sr * a.ld_self + c0);
                     }
                     if (valid) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv;
                 }
@@ -246,13 +276,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
+template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8, bool DENSE = false>
 int launch(const FusedArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(CONCAT ? 2 : 1) * M * (KP + 4) * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void*)layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             sage_set_error("layer_forward: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
@@ -262,7 +292,7 @@ int launch(const FusedArgs& a, hipStream_t st) {
     const int tiles = sage_cdiv(a.n, M);
     const int per_cu = WAVES >= 16 ? 2 : (WAVES == 8 ? 1 : (WREG ? 2 : 4));
     const int grid = min(tiles, per_cu * kNumCU);
-    hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT, DENSE>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     SAGE_CHECK_LAUNCH("layer_fused_kernel");
     return SAGE_OK;
 }
@@ -308,7 +338,7 @@ int sage_launch_layer_fused(const float* table, int64_t table_rows, int64_t ld, 
     }
     if (n == 0) return SAGE_OK;
     const FusedArgs a{table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, self_index,
-                      weight, ldw, out_dim, act, out, ldo, n_off, fin};
+                      table, ld, (int)table_rows, weight, ldw, out_dim, act, out, ldo, n_off, fin};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
     if (!concat) {
         if (kp == 64) return launch_by_rows<64, false>(a, st);

@@ -92,13 +92,100 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(
     }
 }
 
+// ---- column-sliced gather (wide rows, large layers) ------------------------------------------------------
+// Per-XCD L2s are private: with one wave per destination ROW every XCD ends up caching its own copy of the
+// hub rows, the L2 hit rate is ~20 % and 85 % of the gathered bytes come from beyond L2.
+// Here a block owns one SLICE of SL*4 columns (SL lanes x 16 B) of every row it touches, and consecutive
+// blocks -- which the dispatcher deals round-robin over the 8 XCDs -- own different slices.  An XCD then only
+// ever caches its slice of the hot rows (4x more rows per L2 at 256-B slices), which is what lifts the hit rate.
+// Inside a wave, lane group g = lane / SL fetches neighbour g's slice, so one wave-instruction still moves
+// 1 KiB (64/SL neighbours x SL*16 B); the groups' partial sums are combined with xor-shuffles (the wavefront
+// reduction), and group 0 writes the mean.  Placement is a speed assumption only: any block -> XCD map is correct.
+// Measured (config-3 layer 1, 338 k row gathers of 1 KiB): row-per-wave 65 us, 128-B slices 54 us, 256-B slices 45 us.
+template <int SL>
+__global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
+    const float* __restrict__ table, int table_rows, int64_t ld, int dim,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
+    const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice) {
+    using V = __attribute__((ext_vector_type(4))) float;
+    constexpr int NPI = kWave / SL;             // neighbours per wave-instruction
+    constexpr int U = 4;                        // wave-instructions in flight
+    int nn = n;
+    if (n_dev) nn = min(*n_dev + n_off, n);
+    const int lane = sage_lane();
+    const int slice = (int)(blockIdx.x % nslice);
+    const int wave = (int)(((blockIdx.x / nslice) * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)(((gridDim.x / nslice) * blockDim.x) >> 6);
+    const int grp = lane / SL, gl = lane % SL;
+    const int c0 = slice * SL * 4 + gl * 4;     // this lane's columns
+    const bool ok = c0 < dim;                   // dim % 4 == 0 (host-checked)
+    const bool nan_rule = any_nonempty ? (*any_nonempty != 0) : false;
+    const int last_row = table_rows - 1;
+    for (int r = wave; r < nn; r += nwaves) {
+        const int c = min(__builtin_amdgcn_readfirstlane(cnt[r]), kWave);   // k <= 64 (host-checked)
+        int s = -1;
+        if (self_row) {
+            s = self_row[r];
+            if (slot_rows && s >= 0) s = slot_rows[s];
+            s = __builtin_amdgcn_readfirstlane(s);
+        }
+        int myid = (lane < c) ? nbr[(int64_t)r * k + lane] : 0;
+        if (slot_rows) myid = slot_rows[max(myid, 0)];
+        bool extra = s >= 0;
+        if (extra && __any(lane < c && myid == s)) extra = false;           // aggregators.py:50-51: set union
+        myid = min(max(myid, 0), last_row);
+        V acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < c; j0 += NPI * U) {
+            V t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * NPI + grp;
+                const int id = __shfl(myid, min(j, c - 1), kWave);
+                if (ok && j < c) t[u] = *reinterpret_cast<const V*>(table + (int64_t)id * ld + c0);
+                else t[u] = V{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += t[u];
+        }
+        if (extra && ok && grp == 0) acc += *reinterpret_cast<const V*>(table + (int64_t)min(s, last_row) * ld + c0);
+#pragma unroll
+        for (int m = SL; m < kWave; m <<= 1) {
+            acc[0] += __shfl_xor(acc[0], m, kWave);
+            acc[1] += __shfl_xor(acc[1], m, kWave);
+            acc[2] += __shfl_xor(acc[2], m, kWave);
+            acc[3] += __shfl_xor(acc[3], m, kWave);
+        }
+        if (grp == 0 && ok) {
+            const int ceff = c + (extra ? 1 : 0);
+            V res;
+            if (ceff > 0) res = acc * (1.0f / (float)ceff);
+            else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
+            *reinterpret_cast<V*>(out + (int64_t)r * ldo + c0) = res;
+        }
+    }
+}
+
 }  // namespace
+
+bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k) {
+    const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
+    return vec4 && dim >= 128 && n >= 8192 && k <= kWave;
+}
 
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
                             hipStream_t st) {
     if (n == 0) return SAGE_OK;
+    if (sage_gather_is_sliced(dim, ld, ldo, table, out, n, k)) {
+        const int nslice = sage_cdiv(dim, 64);                   // 256-B slices
+        const int blocks = nslice * (kNumCU * 8 / nslice);
+        hipLaunchKernelGGL(gather_mean_sliced_kernel<16>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
+                           n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+        SAGE_CHECK_LAUNCH("gather_mean_sliced_kernel");
+        return SAGE_OK;
+    }
     const int blocks = min(sage_cdiv(n, 4), kNumCU * 8);
     const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
     if (vec4)

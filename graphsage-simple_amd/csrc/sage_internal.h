@@ -28,6 +28,7 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
                             hipStream_t st);
+bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k);
 
 int sage_launch_linear_act(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg, int64_t ld_agg,
                            int32_t dim, const float* weight, int64_t ldw, int32_t out_dim, int32_t act, int32_t n,
@@ -40,6 +41,11 @@ int sage_launch_layer_fused(const float* table, int64_t table_rows, int64_t ld, 
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo,
                             int32_t n_off, sage_finish_t fin, hipStream_t st);
 bool sage_layer_fused_supported(int32_t dim, int32_t out_dim, int32_t concat);
+int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32_t n, const int32_t* n_dev, int32_t concat,
+                            const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
+                            const int32_t* cnt, const int32_t* any_nonempty,
+                            const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
+                            sage_finish_t fin, hipStream_t st);
 
 #ifdef __HIPCC__
 // Called by EVERY block of the forward's last kernel, after its last use of the counters.

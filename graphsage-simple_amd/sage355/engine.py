@@ -144,7 +144,7 @@ class TwoHopEngine:
         self._model_key = None
         model = self._model()
         native.check(native.lib().sage_forward2_layout(model, self.max_batch, self.layout), "forward2_layout")
-        self.workspace = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
+        self.workspace = torch.zeros(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
         native.check(native.lib().sage_forward2_init(model, self.workspace.data_ptr(), self.workspace.numel(), self.max_batch,
                                                      torch.cuda.current_stream().cuda_stream), "forward2_init")
         self._graph = None
@@ -193,3 +193,4 @@ class TwoHopEngine:
             "cnt1": self._view(L.cnt1, L.max_s1, torch.int32)[:n1],
             "h1": self._view(L.h1, L.max_s1 * self.h1, torch.float32).view(L.max_s1, self.h1)[:n1],
         }
+

@@ -278,9 +278,10 @@ int sage_forward2(const sage_model_t* m, void* workspace, size_t workspace_bytes
 
 /* Same forward with hipEvent_t markers around its stages, for in-situ kernel timing
  * (bench.py roofline).  stage_events: 2*SAGE_NUM_STAGES hipEvent_t handles
- * (begin, end for stage 0..3 = outer sample, inner sample, layer 1, layer 2); NULL
- * entries are skipped.  Events are recorded on `stream`. */
-#define SAGE_NUM_STAGES 4
+ * (begin, end for interval 0..4 = outer sample, inner sample, layer-1 gather (split layers
+ * only, else empty), layer-1 contraction or fused layer 1, layer 2); NULL entries are skipped.
+ * Events are recorded on `stream`. */
+#define SAGE_NUM_STAGES 5
 int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes,
                            const int32_t* seeds, int32_t batch, uint64_t seed,
                            float* out, int64_t ldo, sage_stream_t stream,

@@ -175,11 +175,12 @@ def check_engine_against_oracle(graph, table, w1, w2, seeds, k1, k2, concat, sel
 
 
 @pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("d0", [100, 256])      # 256: layer 1 takes the column-sliced gather + dense contraction
 @pytest.mark.parametrize("concat,self_loop", [(False, False), (True, False), (False, True), (True, True)])
-def test_two_hop_small_rmat_all_variants(concat, self_loop, fused):
+def test_two_hop_small_rmat_all_variants(concat, self_loop, fused, d0):
     graph = rmat_graph(14, 300_000, seed=2)
     gen = torch.Generator().manual_seed(0)
-    d0, h1, h2 = 100, 64, 32
+    h1, h2 = 64, 32
     table = torch.randn(graph.num_nodes, d0, generator=gen)
     m = 2 if concat else 1
     w1 = torch.randn(h1, m * d0, generator=gen) / np.sqrt(m * d0)

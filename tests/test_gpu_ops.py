@@ -128,7 +128,8 @@ def test_frontier_is_the_set_union_with_a_consistent_row_map(graph, insert_self)
 
 
 # ------------------------------------------------------------------ gather_mean (a5-a8)
-@pytest.mark.parametrize("dim,k,n", [(256, 15, 3000), (128, 25, 1000), (1433, 5, 300), (50, 25, 700), (64, 100, 200), (4, 1, 65)])
+@pytest.mark.parametrize("dim,k,n", [(256, 15, 3000), (128, 25, 1000), (1433, 5, 300), (50, 25, 700), (64, 100, 200), (4, 1, 65),
+                                     (256, 15, 9000), (128, 25, 8200), (192, 40, 8192), (256, 64, 8300), (256, 70, 8300)])  # >= 8192 rows: column-sliced kernel
 def test_gather_mean_matches_oracle(dim, k, n):
     rs = np.random.default_rng(dim + k)
     rows = 5000
@@ -141,13 +142,13 @@ def test_gather_mean_matches_oracle(dim, k, n):
     assert_close_rowmax(out.cpu(), ref, what=f"gather_mean dim={dim} k={k}")
 
 
-def test_gather_mean_strided_table_slot_rows_and_self_row():
+@pytest.mark.parametrize("rows,dim,k,n", [(900, 96, 9, 500), (3000, 256, 15, 8500)])   # row-per-wave and column-sliced kernels
+def test_gather_mean_strided_table_slot_rows_and_self_row(rows, dim, k, n):
     rs = np.random.default_rng(5)
-    rows, dim, k, n = 900, 96, 9, 500
     big = torch.randn(rows, dim + 32, generator=torch.Generator().manual_seed(1)).to(DEV)
     table = big[:, :dim]                                   # ld = dim + 32
-    perm = rs.permutation(2048).astype(np.int32)           # slot -> row indirection
-    slot_rows = np.full(2048, -1, dtype=np.int32)
+    perm = rs.permutation(4096).astype(np.int32)           # slot -> row indirection
+    slot_rows = np.full(4096, -1, dtype=np.int32)
     slot_rows[perm[:rows]] = np.arange(rows, dtype=np.int32)
     cnt = rs.integers(0, k + 1, size=n).astype(np.int32)
     nbr_row = rs.integers(0, rows, size=(n, k)).astype(np.int32)
