@@ -34,6 +34,14 @@ HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 CACHE_DIR = os.environ.get("SAGE_CACHE", "/tmp/sage_cache")
 
 
+PRESETS = {
+    2: dict(dim=500, hidden1=50, hidden=128, k1=10, k2=25, batch=256),
+    3: dict(scale=20, edges=16_000_000, dim=256, hidden1=128, hidden=128, k1=15, k2=25, batch=4096),
+    4: dict(scale=23, edges=128_000_000, dim=256, hidden1=128, hidden=128, k1=15, k2=25, batch=4096),
+    5: dict(scale=22, edges=62_000_000, dim=100, hidden1=128, hidden=128, k1=20, k2=25, batch=4096, truncate=2_400_000),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,9 +60,20 @@ def parse():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--k1", type=int, default=15)
     ap.add_argument("--k2", type=int, default=25)
+    ap.add_argument("--self-loop", action="store_true", help="GCN-variant aggregator: the node joins its own neighbour set (aggregators.py:50-51)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[] preset: 3 = the bench line (default); 2 = Pubmed topology D0=500 H=50/128 fanout 10/25 "
+                         "B=256; 4 = R-MAT 2^23 / 128 M edges; 5 = ogbn-products-shaped 2.4 M nodes / 62 M edges D0=100 fanout 20/25")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args()
+    given = {a.split("=")[0].lstrip("-").replace("-", "_") for a in sys.argv[1:] if a.startswith("--")}
+    args.hidden1 = args.hidden
+    args.truncate = 0
+    for key, val in PRESETS[args.config].items():       # a preset fills what the command line left at its default
+        if key not in given:
+            setattr(args, key, val)
+    return args
 
 
 class HipEvents:
@@ -83,9 +102,10 @@ def algorithmic_bytes(d0, h1, h2, k1dim, k2dim, b, n_s1, e1, e2, n_r1):
     """SURVEY.md 8(d) / BASELINE.md section 4: compulsory traffic of one forward, and the share of
     its dominant kernel (layer 1: raw rows in, ids in, h1 out, W1)."""
     layer1 = 4 * d0 * n_r1 + 4 * h1 * n_s1 + 4 * e1 + 4 * n_s1 + 4 * h1 * k1dim
+    gather1 = 4 * d0 * n_r1 + 4 * d0 * n_s1 + 4 * e1 + 4 * n_s1       # split layer 1: rows in, ids in, [|S1|, D0] means out
     total = (4 * d0 * n_r1 + 2 * 4 * h1 * n_s1 + 4 * h2 * b + 4 * (e1 + e2) + 16 * (n_s1 + b)
              + 4 * (h1 * k1dim + h2 * k2dim))
-    return total, layer1
+    return total, layer1, gather1
 
 
 def main():
@@ -109,18 +129,31 @@ def main():
     native.lib()
 
     # ---- synthetic inputs: rank 0 generates, the others load its cache ----
+    def make_graph():
+        if args.config == 2:        # real Pubmed topology (edge list shipped as a fixture; features are synthetic)
+            from sage355.graph import CSRGraph
+            z = np.load(os.path.join(REPO, "tests", "golden", "pubmed_topology.npz"))
+            return CSRGraph(z["rowptr"], z["col"], len(z["rowptr"]) - 1)
+        g_ = rmat_graph(args.scale, args.edges, seed=0, cache_dir=CACHE_DIR)
+        if args.truncate:
+            from sage355.graph import truncate_nodes
+            g_ = truncate_nodes(g_, args.truncate)
+        return g_
+
     if rank == 0:
-        graph = rmat_graph(args.scale, args.edges, seed=0, cache_dir=CACHE_DIR)
+        graph = make_graph()
     if dist is not None:
         dist.barrier()
     if rank != 0:
-        graph = rmat_graph(args.scale, args.edges, seed=0, cache_dir=CACHE_DIR)
+        graph = make_graph()
     n = graph.num_nodes
     concat = args.mode == "concat"
     mult = 2 if concat else 1
-    d0, h1, h2, k1, k2, b = args.dim, args.hidden, args.hidden, args.k1, args.k2, args.batch
+    d0, h1, h2, k1, k2, b = args.dim, args.hidden1, args.hidden, args.k1, args.k2, args.batch
     gen = torch.Generator(device=dev).manual_seed(0)
     table = torch.randn(n, d0, generator=gen, device=dev)
+    if args.config == 2:            # Pubmed features rand * Bernoulli(0.1)
+        table = torch.rand(n, d0, generator=gen, device=dev) * (torch.rand(n, d0, generator=gen, device=dev) < 0.1)
     wgen = torch.Generator().manual_seed(0)
     w1 = ((torch.rand(h1, mult * d0, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h1 + mult * d0))).to(dev)
     w2 = ((torch.rand(h2, mult * h1, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h2 + mult * h1))).to(dev)
@@ -134,7 +167,8 @@ def main():
     sampler_seed = [0x5A6E355 + 1000003 * rank + i for i in range(total_steps)]
 
     nstreams = max(1, args.streams)
-    engines = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, fused=not args.unfused, max_batch=b)
+    engines = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, agg_self_loop=args.self_loop, fused=not args.unfused,
+                            max_batch=b)
                for _ in range(nstreams)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     outs = [torch.empty(b, h2, device=dev) for _ in range(nstreams)]
@@ -149,6 +183,7 @@ def main():
         s1, nbr1, cnt1 = it["s1_nodes"].cpu().numpy(), it["nbr1"].cpu().numpy(), it["cnt1"].cpu().numpy()
         ref = ref_sparse.two_hop_forward(table.cpu(), w1.cpu(), w2.cpu(), seeds_host[0], it["nbr2"].cpu().numpy(),
                                          it["cnt2"].cpu().numpy(), s1[first:], nbr1[first:], cnt1[first:], gcn=not concat,
+                                         agg_gcn=args.self_loop,
                                          seed_nbr1=nbr1[:first] if concat else None, seed_cnt1=cnt1[:first] if concat else None)
         scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-30)
         parity_err = ((o.double() - ref).abs() / scale).max().item()
@@ -229,7 +264,7 @@ def main():
                 f = flags[s]
                 f.zero_()
                 f.scatter_(0, ids.reshape(-1), 1)
-                if concat:
+                if concat or args.self_loop:
                     s1 = e._view(L.s1_nodes, L.max_s1, torch.int32)
                     f.scatter_(0, torch.where(live, s1, n).long(), 1)
                 stats[i, 0] = cnt2.sum()
@@ -244,14 +279,16 @@ def main():
             for j in range(10):
                 he.destroy(arr[j])
         stage /= args.steps
-        split = stage[2] > 1e-4      # layer 1 ran as column-sliced gather + dense contraction
+        split = bool(engines[0].layout.layer1_split)      # layer 1 ran as column-sliced gather + dense contraction
+        if not split:
+            stage[2] = 0.0
         layer1_ms = float(stage[2]) if split else float(stage[3])
         st = stats[args.warmup:].cpu().numpy().astype(np.float64)
         tot = l1 = 0.0
         for e2, n_s1, e1, n_r1 in st:
-            t_, l_ = algorithmic_bytes(d0, h1, h2, mult * d0, mult * h1, b, n_s1, e1, e2, n_r1)
+            t_, l_, g_ = algorithmic_bytes(d0, h1, h2, mult * d0, mult * h1, b, n_s1, e1, e2, n_r1)
             tot += t_
-            l1 += l_
+            l1 += g_ if split else l_
         tot /= args.steps
         l1 /= args.steps
         sizes = st.mean(0)
@@ -289,8 +326,12 @@ def main():
             "metric": "node-embeddings/sec (2-hop forward)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: R-MAT 2^{args.scale} nodes / {args.edges} edges, {d0}-dim fp32 features, "
-                                   f"2-layer GraphSAGE-mean {args.mode} encoder H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: " + (
+                           "Pubmed topology (19717 nodes)" if args.config == 2 else
+                           f"R-MAT 2^{args.scale} / {args.edges} edges" + (f" truncated to {n} nodes" if args.truncate else f" ({n} nodes)"))
+                           + f", {graph.nnz} directed nnz, {d0}-dim fp32 features, 2-layer GraphSAGE-mean {args.mode} encoder"
+                           + (" + self-loop (GCN-variant) aggregator" if args.self_loop else "")
+                           + f" H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU",
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
                        "streams_in_flight": nstreams, "fused_layers": not args.unfused, "hip_graph_replay": use_graph,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},

@@ -9,8 +9,6 @@
 //   * one barrier per tile (the double buffer makes the second one unnecessary);
 //   * operands as in sage_fused.hip: lane (i = l&31, h = l>>5) supplies A[i][8q+4h+t] / W[n0+i][8q+4h+t]
 //     to MFMA 4q+t; LDS rows padded by one ds_read_b128 width.
-#include <stdlib.h>
-
 #include "sage_internal.h"
 
 namespace {
@@ -28,15 +26,20 @@ struct DenseArgs {
     sage_finish_t fin;
 };
 
+// Concat encoder (K = 2*dim): with KP <= 128 a wave keeps BOTH chunks of its W slice in registers; at KP = 256 the
+// block grows to 8 waves, waves 4-7 own the second K chunk (their own W slice in registers, their own partial
+// accumulator) and hand their partial sums to waves 0-3 through LDS -- W is never re-read per tile.
 template <int KP, bool CONCAT>
-__global__ __launch_bounds__(256, 2) void dense_layer_kernel(const DenseArgs a) {
-    constexpr int M = 32, WAVES = 4;
+__global__ __launch_bounds__((CONCAT && KP == 256) ? 512 : 256, 2) void dense_layer_kernel(const DenseArgs a) {
+    constexpr bool KSPLIT = CONCAT && KP == 256;       // split K across two wave groups
+    constexpr int M = 32, WAVES = KSPLIT ? 8 : 4;
     constexpr int LDA = KP + 4;
     constexpr int CHUNKS = CONCAT ? 2 : 1;
+    constexpr int WCH = KSPLIT ? 1 : CHUNKS;           // K chunks one wave contracts
     constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
     constexpr int BUF = CHUNKS * M * LDA;                   // floats per LDS buffer
     static_assert(RPW % RPP == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][CHUNKS][M][LDA]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][CHUNKS][M][LDA] (+ [4][16][64] partials when KSPLIT)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nn = a.n;
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const DenseArgs a) 
     if ((int)blockIdx.x < ntiles) {
         const bool nan_rule = (a.cnt && a.any_nonempty) ? (*a.any_nonempty != 0) : false;
         const int i32 = lane & 31, h = lane >> 5;
-        const int n0 = wave * 32;
+        const int n0 = (wave & 3) * 32;
+        const int kgroup = wave >> 2;                   // 0, or 1 for the second K chunk (KSPLIT)
         const bool mfma_wave = n0 < a.out_dim;
         const int lg = lane & (LG - 1), sg = lane / LG;
         const int c0 = lg * 4;
@@ -53,17 +57,18 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const DenseArgs a) 
         const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
         const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
 
-        float breg[KP / 2];
-        auto load_w = [&](int chunk) {
+        float breg[WCH][KP / 2];
+#pragma unroll
+        for (int wc = 0; wc < WCH; ++wc) {
+            const int chunk = KSPLIT ? kgroup : wc;
 #pragma unroll
             for (int q = 0; q < KP / 8; ++q) {
                 const int kc = 8 * q + 4 * h;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (wrow_ok && kc < a.dim) v = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
-                breg[4 * q + 0] = v[0]; breg[4 * q + 1] = v[1]; breg[4 * q + 2] = v[2]; breg[4 * q + 3] = v[3];
+                breg[wc][4 * q + 0] = v[0]; breg[wc][4 * q + 1] = v[1]; breg[wc][4 * q + 2] = v[2]; breg[wc][4 * q + 3] = v[3];
             }
-        };
-        if (CHUNKS == 1) load_w(0);
+        }
 
         f32x4 xr[PASSES], sr[CONCAT ? PASSES : 1];
         auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
@@ -103,22 +108,36 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const DenseArgs a) 
             __syncthreads();
             const int next = tile + gridDim.x;
             if (next < ntiles) request_tile(next);            // in flight during the MFMA loop below
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             if (mfma_wave) {
-                f32x16 acc;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-                for (int chunk = 0; chunk < CHUNKS; ++chunk) {
-                    if (CHUNKS > 1) load_w(chunk);
+                for (int wc = 0; wc < WCH; ++wc) {
+                    const int chunk = KSPLIT ? kgroup : wc;
                     const float* abase = buf + (chunk * M + i32) * LDA + 4 * h;
 #pragma unroll
                     for (int q = 0; q < KP / 8; ++q) {
                         const f32x4 av = *reinterpret_cast<const f32x4*>(abase + 8 * q);
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], breg[4 * q + t], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], breg[wc][4 * q + t], acc, 0, 0, 0);
                     }
                 }
+            }
+            if constexpr (KSPLIT) {                          // waves 4-7 -> LDS -> waves 0-3
+                float* red = lds + 2 * BUF + (wave & 3) * 16 * 64;
+                if (kgroup == 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[e * 64 + lane] = acc[e];
+                }
+                __syncthreads();
+                if (kgroup == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] += red[e * 64 + lane];
+                }
+            }
+            if (mfma_wave && kgroup == 0) {
                 const int col = n0 + i32;
                 if (col < a.out_dim) {
 #pragma unroll
@@ -135,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const DenseArgs a) 
 
 template <int KP, bool CONCAT>
 int launch(const DenseArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (CONCAT ? 2 : 1) * 32 * (KP + 4) * sizeof(float);
+    constexpr bool KSPLIT = CONCAT && KP == 256;
+    constexpr size_t lds = ((size_t)2 * (CONCAT ? 2 : 1) * 32 * (KP + 4) + (KSPLIT ? 4 * 16 * 64 : 0)) * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_layer_kernel<KP, CONCAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -145,10 +165,10 @@ int launch(const DenseArgs& a, hipStream_t st) {
         }
         configured = true;
     }
-    static const int per_cu_env = getenv("SAGE_DENSE_BLOCKS") ? atoi(getenv("SAGE_DENSE_BLOCKS")) : 0;   // experiment switch
-    const int per_cu = per_cu_env ? per_cu_env : ((lds > 80 * 1024) ? 1 : 2);
-    const int grid = min(sage_cdiv(a.n, 32), per_cu * kNumCU);
-    hipLaunchKernelGGL((dense_layer_kernel<KP, CONCAT>), dim3(grid), dim3(256), lds, st, a);
+    // one persistent block per CU (24.9 us) beat two (26.3 us) on the config-3 contraction: the prefetch only pays
+    // when a block owns >= 2 tiles, and one block per CU leaves wave slots for another batch's kernels
+    const int grid = min(sage_cdiv(a.n, 32), kNumCU);
+    hipLaunchKernelGGL((dense_layer_kernel<KP, CONCAT>), dim3(grid), dim3(KSPLIT ? 512 : 256), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_layer_kernel");
     return SAGE_OK;
 }

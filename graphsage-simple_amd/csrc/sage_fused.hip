@@ -42,9 +42,7 @@ struct FusedArgs {
 // own output columns [32(w&3), +32) of 32-row block(s) w>>2); WREG: keep the wave's W slice in
 // VGPRs for the whole kernel (big layers) or stream it from L2 inside the MFMA loop (small
 // layers, where 16 waves per block buy gather parallelism and cap the VGPR budget at 128).
-// DENSE: `table` already holds one aggregated row per destination (the column-sliced gather wrote it), so
-// phase A is a plain copy of the tile's rows and the kernel is the contraction [n, K] x W^T + act.
-template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8, bool DENSE = false>
+template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
 __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void layer_fused_kernel(const FusedArgs a) {
     constexpr int LDA = KP + 4;                 // floats per LDS row
     constexpr int CHUNKS = CONCAT ? 2 : 1;
@@ -80,7 +78,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
 
     // ---- W slice -> registers (per K chunk): breg[4q+t] = W[n0+i][chunk*dim + 8q + 4h + t]
-    float breg[WREG ? KP / 2 : 4];
+    constexpr bool WALL = WREG && CHUNKS == 2 && KP <= 128;   // concat, narrow: both K chunks of the slice stay in registers
+    float breg[WREG ? (WALL ? KP : KP / 2) : 4];
     auto load_wq = [&](int chunk, int q) {
         const int kc = 8 * q + 4 * h;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -89,46 +88,21 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     };
     auto load_w = [&](int chunk) {
         if constexpr (WREG) {
+            const int o = WALL ? chunk * (KP / 2) : 0;
 #pragma unroll
             for (int q = 0; q < KP / 8; ++q) {
                 const f32x4 v = load_wq(chunk, q);
-                breg[4 * q + 0] = v[0]; breg[4 * q + 1] = v[1]; breg[4 * q + 2] = v[2]; breg[4 * q + 3] = v[3];
+                breg[o + 4 * q + 0] = v[0]; breg[o + 4 * q + 1] = v[1]; breg[o + 4 * q + 2] = v[2]; breg[o + 4 * q + 3] = v[3];
             }
         }
     };
     if (CHUNKS == 1) load_w(0);
+    if (WALL) { load_w(0); load_w(1); }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * M;
         // ------------------------------------------------------------ phase A: gather-mean -> LDS
-        if constexpr (DENSE) {
-            // every wave copies its RPW rows into the tile; all PASSES wave-instructions are in flight at once
-            f32x4 t[PASSES], sv[CONCAT ? PASSES : 1];
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int rsub = p * RPP + sg;
-                const int g = row0 + wave * RPW + rsub;
-                const bool valid = rsub < RPW && g < nn && col_ok;
-                t[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (valid) t[p] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)g * a.ld + c0);
-                if (CONCAT) {
-                    sv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (valid) {
-                        const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
-                        sv[p] = *reinterpret_cast<const f32x4*>(a.self_tab + sr * a.ld_self + c0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int rsub = p * RPP + sg;
-                const int r = wave * RPW + rsub;
-                if (rsub < RPW && col_pad) {
-                    *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + r) * LDA + c0) = t[p];
-                    if (CONCAT) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = sv[p];
-                }
-            }
-        } else if constexpr (RPP == 1) {
+        if constexpr (RPP == 1) {
             // 256-wide rows: the whole wave is on one row, ids are wave-uniform (v_readlane -> scalar address)
             for (int rr = 0; rr < RPW; ++rr) {
                 const int r = wave + WAVES * rr;        // row inside the tile
@@ -243,7 +217,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
                 for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
 #pragma unroll
             for (int chunk = 0; chunk < CHUNKS; ++chunk) {
-                if (CHUNKS > 1) load_w(chunk);
+                if (CHUNKS > 1 && !WALL) load_w(chunk);
+                const int bo = WALL ? chunk * (KP / 2) : 0;
                 const float* abase = lds + (chunk * M + mb0 * 32 + i32) * LDA + 4 * h;
 #pragma unroll
                 for (int q = 0; q < KP / 8; ++q) {
@@ -251,7 +226,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
 #pragma unroll
                     for (int b = 0; b < MBW; ++b) av[b] = *reinterpret_cast<const f32x4*>(abase + b * 32 * LDA + 8 * q);
                     f32x4 bv;
-                    if constexpr (WREG) bv = f32x4{breg[4 * q], breg[4 * q + 1], breg[4 * q + 2], breg[4 * q + 3]};
+                    if constexpr (WREG) bv = f32x4{breg[bo + 4 * q], breg[bo + 4 * q + 1], breg[bo + 4 * q + 2], breg[bo + 4 * q + 3]};
                     else bv = load_wq(chunk, q);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -276,13 +251,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8, bool DENSE = false>
+template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
 int launch(const FusedArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(CONCAT ? 2 : 1) * M * (KP + 4) * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (lds > 64 * 1024 &&
-            hipFuncSetAttribute((const void*)layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             sage_set_error("layer_forward: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
@@ -292,7 +267,7 @@ int launch(const FusedArgs& a, hipStream_t st) {
     const int tiles = sage_cdiv(a.n, M);
     const int per_cu = WAVES >= 16 ? 2 : (WAVES == 8 ? 1 : (WREG ? 2 : 4));
     const int grid = min(tiles, per_cu * kNumCU);
-    hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT, DENSE>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     SAGE_CHECK_LAUNCH("layer_fused_kernel");
     return SAGE_OK;
 }
@@ -314,7 +289,7 @@ int launch_by_rows(const FusedArgs& a, hipStream_t st) {
         else if constexpr (KP == 256) return launch<KP, 32, 4, false, CONCAT>(a, st);
         else return launch<KP, 64, 4, true, CONCAT>(a, st);
     }
-    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, 16, true, CONCAT>(a, st);
+    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, 16, true, CONCAT, 6>(a, st);    // 6 in flight: stays inside the 128-VGPR budget of a 16-wave block
     else return launch<KP, 32, 8, true, CONCAT>(a, st);
 }
 

@@ -55,7 +55,7 @@ class WsLayout(Structure):
                 ("nbr2", c_size_t), ("slot2", c_size_t), ("cnt2", c_size_t), ("self_slot2", c_size_t),
                 ("row2", c_size_t), ("self_row2", c_size_t),
                 ("nbr1", c_size_t), ("cnt1", c_size_t),
-                ("agg1", c_size_t), ("h1", c_size_t), ("agg2", c_size_t)]
+                ("agg1", c_size_t), ("h1", c_size_t), ("agg2", c_size_t), ("layer1_split", c_int32)]
 
 
 _lib = None

@@ -256,6 +256,8 @@ typedef struct {
     size_t  agg1;         /* float [max_s1, d0]   (two-launch form only)     */
     size_t  h1;           /* float [max_s1, h1]                               */
     size_t  agg2;         /* float [B, h1]        (two-launch form only)     */
+    int32_t layer1_split; /* 1: layer 1 runs as column-sliced gather -> agg1 -> dense contraction;
+                             0: one fused launch (or the generic two-launch form when unsupported)   */
 } sage_ws_layout_t;
 
 int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sage_ws_layout_t* layout_host);
