@@ -18,15 +18,15 @@ __global__ __launch_bounds__(256) void gm_sliced(const float* __restrict__ table
         const int c = __builtin_amdgcn_readfirstlane(cnt[r]);
         const int myid = lane < c ? nbr[(int64_t)r * k + lane] : 0;
         f4 acc = {0, 0, 0, 0};
-        f4 t[4];
+        f4 t[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int j = u * NPI + grp;
             const int id = __shfl(myid, j < c ? j : 0, 64);
             t[u] = (j < c && u * NPI < c) ? *reinterpret_cast<const f4*>(table + (int64_t)id * 256 + coff) : f4{0, 0, 0, 0};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc += t[u];
+        for (int u = 0; u < 8; ++u) acc += t[u];
         // reduce across the NPI lane groups
 #pragma unroll
         for (int m = SL; m < 64; m <<= 1) {
@@ -42,5 +42,6 @@ __global__ __launch_bounds__(256) void gm_sliced(const float* __restrict__ table
 extern "C" void run_sliced(int sl, int blocks, const float* table, const int32_t* nbr, const int32_t* cnt, int k, int n, float* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (sl == 8) hipLaunchKernelGGL(gm_sliced<8>, dim3(blocks), dim3(256), 0, st, table, nbr, cnt, k, n, out);
+    else if (sl == 32) hipLaunchKernelGGL(gm_sliced<32>, dim3(blocks), dim3(256), 0, st, table, nbr, cnt, k, n, out);
     else hipLaunchKernelGGL(gm_sliced<16>, dim3(blocks), dim3(256), 0, st, table, nbr, cnt, k, n, out);
 }
