@@ -66,6 +66,8 @@ def parse():
                          "B=256; 4 = R-MAT 2^23 / 128 M edges; 5 = ogbn-products-shaped 2.4 M nodes / 62 M edges D0=100 fanout 20/25")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsing N > 1 on a 1-GPU box)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
     given = {a.split("=")[0].lstrip("-").replace("-", "_") for a in sys.argv[1:] if a.startswith("--")}
     args.hidden1 = args.hidden
@@ -116,12 +118,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL; only barriers + one MAX all-reduce of the time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL; only barriers + one MAX all-reduce of the time
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from sage355 import native, ops
     from sage355.engine import TwoHopEngine
@@ -225,7 +233,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3

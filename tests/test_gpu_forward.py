@@ -231,3 +231,41 @@ def test_graph_replay_of_queued_batches_equals_direct_calls():
                 eng.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(out, want[i]), f"concat={concat} round {rnd} batch {i}"
+
+
+def test_integration_md_ctypes_stub():
+    """The ctypes stub INTEGRATION.md shows a maintainer (section B), verbatim in spirit: raw CDLL, raw pointers."""
+    import ctypes
+    from sage355 import native
+    L = ctypes.CDLL(native.LIB_PATH)
+    P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.sage_last_error.restype = ctypes.c_char_p
+    L.sage_sample_neighbors.argtypes = [P, P, I64, P, I32, P, I32, ctypes.c_uint64, ctypes.c_uint32, P, P, P, P, I32, P, P, P]
+    L.sage_layer_forward.argtypes = [P, I64, I64, I32, P, P, I32, I32, P, P, P, P, I32, P, P, I64, I32, I32, P, I64, P]
+
+    def encoder_forward(table, rowptr, col, nodes_i32, W, k, seed, gcn=True):
+        n, D, H = nodes_i32.numel(), table.shape[1], W.shape[0]
+        nbr = torch.empty(n, k, dtype=torch.int32, device="cuda")
+        cnt = torch.empty(n, dtype=torch.int32, device="cuda")
+        out = torch.empty(n, H, device="cuda")
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+        rc = L.sage_sample_neighbors(p(rowptr), p(col), rowptr.numel() - 1, p(nodes_i32), n, None, k, seed, 1,
+                                     p(nbr), p(cnt), None, None, 0, None, None, st)
+        assert rc == 0, L.sage_last_error()
+        rc = L.sage_layer_forward(p(table), table.shape[0], table.stride(0), D, p(nbr), p(cnt), k, n, None, None, None, None,
+                                  0 if gcn else 1, None if gcn else p(nodes_i32), p(W), W.stride(0), H, 0, p(out), H, st)
+        assert rc == 0, L.sage_last_error()
+        return out.t(), nbr, cnt
+
+    graph = rmat_graph(13, 150_000, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    table = torch.randn(graph.num_nodes, 128, generator=gen)
+    rowptr, col = graph.to(DEV)
+    nodes = torch.from_numpy(np.random.default_rng(2).choice(np.nonzero(graph.degrees() > 0)[0], 600, replace=False).astype(np.int32))
+    for gcn in (True, False):
+        W = torch.randn(64, 128 if gcn else 256, generator=gen) / 12
+        out, nbr, cnt = encoder_forward(table.to(DEV), rowptr, col, nodes.to(DEV), W.to(DEV), 10, 77, gcn)
+        agg = ref_sparse.gather_mean(table, nbr.cpu().numpy(), cnt.cpu().numpy())
+        ref = ref_sparse.linear_act(None if gcn else table[nodes.long()], agg, W)
+        assert_close_rowmax(out.t().cpu(), ref, what=f"INTEGRATION.md stub gcn={gcn}")
