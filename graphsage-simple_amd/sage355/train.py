@@ -60,7 +60,7 @@ def build_model(feat_data, adj_lists, num_classes, hidden1=50, hidden2=128, num_
 
 
 def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, batch_size=128, ref_batching=False, lr=0.7,
-                 model=None, verbose=True, sample_seed=None, **model_kwargs):
+                 model=None, verbose=True, sample_seed=None, return_model=False, **model_kwargs):
     """-> dict(f1_micro, f1_macro, mean_batch_time, losses).  Mirrors run_model (model.py:184-259).
     `seed` seeds numpy (the split) and Python's random (shuffles + neighbour sampling) as model.py:192-193
     does; `sample_seed` reseeds only Python's random, to vary the sampling stream on a fixed split."""
@@ -106,6 +106,8 @@ def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, ba
     truth = np.asarray(labels)[val].reshape(-1)
     res = {"f1_micro": float(f1_score(truth, pred, average="micro")), "f1_macro": float(f1_score(truth, pred, average="macro")),
            "mean_batch_time": float(np.mean(times)) if times else 0.0, "losses": losses, "test_nodes": test}
+    if return_model:
+        res["model"] = model
     if verbose and rank == 0:
         print("Validation F1 micro:", res["f1_micro"])
         print("Validation F1 macro:", res["f1_macro"])

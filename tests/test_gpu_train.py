@@ -59,3 +59,36 @@ def test_plain_batching_and_eval_fast_path():
     res = run_training(feats, labels, g.to_adj_lists(), 7, seed=1, epochs=3, batch_size=128, ref_batching=False, verbose=False)
     assert np.mean(res["losses"][-5:]) < 0.6 * np.mean(res["losses"][:5])
     assert res["f1_micro"] > 0.85
+
+
+def _train_rank(rank, world, port, tmp):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import io
+    from contextlib import redirect_stdout
+    from sage355 import dist
+    dist.init_from_env(backend="gloo")          # both ranks share cuda:0 here; on a node it is nccl, one GPU per rank
+    g, feats, labels = cora()
+    torch.manual_seed(0)                        # same initial weights; broadcast_params makes that explicit anyway
+    with redirect_stdout(io.StringIO()):
+        res = run_training(feats, labels, g.to_adj_lists(), 7, seed=1, sample_seed=50 + rank, epochs=2, batch_size=256,
+                           verbose=False, return_model=True)
+    w = torch.cat([p.detach().reshape(-1).cpu() for p in res["model"].parameters() if p.requires_grad])
+    torch.save({"w": w, "f1": res["f1_micro"], "first": res["losses"][0], "last": res["losses"][-1]}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_seed_sharded_training_keeps_replicas_identical(tmp_path):
+    """Each rank embeds its shard of every mini-batch (own sampler stream) and the weight gradients are summed
+    with one all-reduce per step: replicas must stay bit-identical and still learn."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_train_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a["w"], b["w"]), "replicas diverged"
+    assert a["last"] < 0.6 * a["first"] and a["f1"] > 0.8
