@@ -1,0 +1,106 @@
+"""CPU tests of the host-side logic around the path: graph ingestion, the stand-in dataset,
+the bench's byte accounting, and the harness pieces that do not need a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from sage355 import graph as G
+from sage355.datasets import standin_citation
+from util import GOLDEN_DIR
+
+
+def test_adj_lists_csr_round_trip_and_canonical_form():
+    adj = {0: {3, 1, 2}, 1: {0}, 2: {0, 2}, 3: {0}, 5: set()}      # node 4 missing, 5 empty, self loop on 2
+    g = G.csr_from_adj_lists(adj)
+    assert g.num_nodes == 6 and g.nnz == 7
+    assert g.neighbors(0).tolist() == [1, 2, 3] and g.neighbors(2).tolist() == [0, 2]      # sorted rows, self loop kept
+    assert g.neighbors(4).size == 0 and g.neighbors(5).size == 0
+    back = g.to_adj_lists()
+    for v in range(6):
+        assert back[v] == adj.get(v, set())
+    assert g.rowptr.dtype == np.int64 and g.col.dtype == np.int32
+
+
+def test_edges_are_symmetrised_deduplicated_and_self_loops_kept():
+    g = G.csr_from_edges([0, 0, 1, 2, 2], [1, 1, 0, 2, 3], 4)          # duplicate edge, reversed duplicate, self loop
+    assert g.to_adj_lists() == {0: {1}, 1: {0}, 2: {2, 3}, 3: {2}}
+    g2 = G.csr_from_edges([0, 2], [1, 2], 3, drop_self_loops=True)
+    assert g2.to_adj_lists() == {0: {1}, 1: {0}, 2: set()}
+
+
+def test_edge_list_readers(tmp_path):
+    """model.py:303-310 (tab/space pairs) and model.py:449-458 (Pubmed .tab) formats; ids by first appearance."""
+    p = tmp_path / "x.cites"
+    p.write_text("35\t1033\n35\t103482\n1033 103482\n9 9\n")
+    g, names = G.read_edge_list(str(p))
+    assert names.tolist() == ["35", "1033", "103482", "9"]
+    assert g.to_adj_lists() == {0: {1, 2}, 1: {0, 2}, 2: {0, 1}, 3: {3}}
+    q = tmp_path / "p.tab"
+    q.write_text("DIRECTED\tcites\nNO_FEATURES\n1\tpaper:19127292\t|\tpaper:17363749\n2\tpaper:19668377\t|\tpaper:19127292\n")
+    g, names = G.read_edge_list(str(q), fmt="pubmed")
+    assert names.tolist() == ["19127292", "17363749", "19668377"]
+    assert g.to_adj_lists() == {0: {1, 2}, 1: {0}, 2: {0}}
+
+
+def test_topology_fixtures_match_the_survey_statistics():
+    """Cora 2708 nodes / sum of degrees 10556 / max 168; Pubmed 19717 / 88651 / 171."""
+    for name, n, nnz, dmax in (("cora", 2708, 10556, 168), ("pubmed", 19717, 88651, 171)):
+        z = np.load(os.path.join(GOLDEN_DIR, f"{name}_topology.npz"))
+        g = G.CSRGraph(z["rowptr"], z["col"], len(z["rowptr"]) - 1)
+        deg = g.degrees()
+        assert (g.num_nodes, g.nnz, int(deg.max()), int(deg.min())) == (n, nnz, dmax, 1)
+        src = np.repeat(np.arange(n), deg)
+        fwd = set(zip(src.tolist(), g.col.tolist()))
+        assert all((b, a) in fwd for a, b in list(fwd)[:2000])      # symmetric
+
+
+def test_rmat_generator_is_deterministic_symmetric_and_loop_free(tmp_path):
+    a = G.rmat_graph(12, 40_000, seed=3)
+    b = G.rmat_graph(12, 40_000, seed=3, cache_dir=str(tmp_path))
+    c = G.rmat_graph(12, 40_000, seed=3, cache_dir=str(tmp_path))     # from the cache
+    for g in (b, c):
+        assert np.array_equal(a.rowptr, g.rowptr) and np.array_equal(a.col, g.col)
+    src = np.repeat(np.arange(a.num_nodes), a.degrees())
+    assert not (src == a.col).any()
+    key = set((src * a.num_nodes + a.col).tolist())
+    assert all((int(d) * a.num_nodes + int(s)) in key for s, d in zip(src[:3000], a.col[:3000]))
+    assert a.degrees().max() > 50 * max(1, np.median(a.degrees()))      # power-law-ish skew
+    t = G.truncate_nodes(a, 3000)
+    assert t.num_nodes == 3000 and t.col.max() < 3000 and t.nnz < a.nnz
+
+
+def test_standin_dataset_is_deterministic_and_learnable_in_principle():
+    z = np.load(os.path.join(GOLDEN_DIR, "cora_topology.npz"))
+    g = G.CSRGraph(z["rowptr"], z["col"], len(z["rowptr"]) - 1)
+    f1, l1 = standin_citation(g, seed=0)
+    f2, l2 = standin_citation(g, seed=0)
+    assert np.array_equal(f1, f2) and np.array_equal(l1, l2)
+    assert f1.shape == (2708, 1433) and l1.shape == (2708, 1) and set(np.unique(l1)) == set(range(7))
+    assert set(np.unique(f1)) == {0.0, 1.0} and 10 < f1.sum(1).mean() < 18
+    # labels follow the topology: most edges join same-label nodes
+    src = np.repeat(np.arange(g.num_nodes), g.degrees())
+    assert (l1[src, 0] == l1[g.col, 0]).mean() > 0.8
+
+
+def test_bench_byte_accounting_matches_the_survey_worked_example():
+    """B=4096, E2=39095, |S1|=23657, E1=339183, |R1|=106339 -> 136.9 MB per forward."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(GOLDEN_DIR), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    total, layer1, gather1 = bench.algorithmic_bytes(256, 128, 128, 256, 128, 4096, 23657, 339183, 39095, 106339)
+    assert abs(total - 136.9e6) < 0.01 * 136.9e6        # the formula, term for term; the survey rounds its example
+    assert layer1 < total and gather1 == 4 * 256 * 106339 + 4 * 256 * 23657 + 4 * 339183 + 4 * 23657
+
+
+def test_training_split_and_batching_follow_the_reference():
+    """model.py:229-234 (10/10/80 split of a seeded permutation) and model.py:244 (the `max` batches)."""
+    np.random.seed(1)
+    perm = np.random.permutation(2708)
+    assert len(perm[:270]) == 270 and len(perm[270:541]) == 271 and len(perm[541:]) == 2167
+    train_num, bs = 2167, 128
+    ref_sizes = [len(list(range(train_num))[b:max(train_num, b + bs)]) for b in range(0, train_num, bs)]
+    assert ref_sizes[:3] == [2167, 2039, 1911] and ref_sizes[-1] == 119 and len(ref_sizes) == 17
+    plain = [min(train_num, b + bs) - b for b in range(0, train_num, bs)]
+    assert plain[0] == 128 and plain[-1] == 119 and sum(plain) == train_num
