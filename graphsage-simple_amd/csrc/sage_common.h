@@ -73,7 +73,11 @@ __device__ inline int sage_hash_insert(int32_t* __restrict__ keys, uint32_t mask
     uint32_t slot = sage_hash_slot((uint32_t)id, mask);
     won = false;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
-        const int32_t seen = atomicCAS(&keys[slot], -1, id);
+        // look before the CAS: a hub id is inserted by hundreds of lanes of one batch (measured: the outer hop's
+        // insert took 11-28 us depending on the batch's hubs), and same-address atomics serialise at ~12 ns each
+        // while L2-served loads of one word do not.  Agent scope = bypass the (never refreshed) L1.
+        int32_t seen = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == -1) seen = atomicCAS(&keys[slot], -1, id);
         if (seen == -1) { won = true; return (int)slot; }
         if (seen == id) return (int)slot;
         slot = (slot + 1) & mask;
@@ -82,6 +86,38 @@ __device__ inline int sage_hash_insert(int32_t* __restrict__ keys, uint32_t mask
 }
 
 __device__ inline int sage_lane() { return (int)(threadIdx.x & (kWave - 1)); }
+
+__device__ inline uint32_t sage_philox_word(const Philox4& p, int w) {
+    return w == 0 ? p.v[0] : w == 1 ? p.v[1] : w == 2 ? p.v[2] : p.v[3];
+}
+
+// Fixed-fanout draw for one node by a group of G lanes (lane gl = sample slot gl, k <= G): returns the lane's
+// position in the node's CSR row.  deg <= k: the whole row in CSR order.  deg > k (`floyd`): Floyd's subset
+// algorithm -- step i draws t_i in [0, deg-k+i] (Philox4x32-10, counter (v, tag, i/4), word i%4) and takes it
+// unless one of the i earlier picks already is t_i, then takes deg-k+i: one group-wide compare + ballot per step.
+// Must be called by every lane of the wave (shuffles / ballots); bit-identical to oracle/sampler_ref.c.
+template <int G>
+__device__ inline uint32_t sage_group_positions(bool floyd, int64_t deg, int k, int32_t v, uint32_t tag, uint32_t key0, uint32_t key1,
+                                                int gl, int lane) {
+    uint32_t pos = (uint32_t)gl;
+    if (__any(floyd)) {
+        const uint32_t ji = (uint32_t)(deg - (int64_t)k) + (uint32_t)gl;
+        uint32_t ti = 0;
+        if (floyd && gl < k) {
+            const Philox4 p = philox4x32_10((uint32_t)v, tag, (uint32_t)(gl >> 2), 0u, key0, key1);
+            ti = sage_bounded(sage_philox_word(p, gl & 3), ji + 1u);
+        }
+        uint32_t chosen = ti;
+        for (int i = 1; i < k; ++i) {
+            const uint32_t t = (uint32_t)__shfl((int)ti, i, G);
+            const unsigned long long b = __ballot(floyd && gl < i && chosen == t);
+            const unsigned long long gb = (G == kWave) ? b : ((b >> (lane - gl)) & ((1ull << (G & 63)) - 1ull));
+            if (gl == i) chosen = gb ? ji : ti;
+        }
+        if (floyd) pos = chosen;
+    }
+    return pos;
+}
 
 __device__ inline float sage_activate(float v, int act) {
     if (act == SAGE_ACT_RELU) return v < 0.f ? 0.f : v;             // NaN stays NaN (torch.relu)

@@ -54,10 +54,6 @@ struct ResolveJob {
     int32_t* hash_keys;
 };
 
-__device__ inline uint32_t philox_word(const Philox4& p, int w) {
-    return w == 0 ? p.v[0] : w == 1 ? p.v[1] : w == 2 ? p.v[2] : p.v[3];
-}
-
 // G lanes per node (k <= G).  SAMPLE: draw from the CSR row; otherwise ids come from
 // (in_nbr, in_cnt).  FRONTIER: also insert the ids into the hash and reserve frontier rows.
 template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
@@ -70,6 +66,9 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
     FrontierDev f, int insert_self, int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot, BatchSrc bs,
     int n_off, ResolveJob rj) {
     __shared__ int blk[2];                 // [0] rows claimed by this block, [1] their base row
+    constexpr int LT = FRONTIER ? 4 * THREADS : 1;      // block-local dedupe table (ids per block <= THREADS + THREADS/G)
+    __shared__ int32_t lkeys[LT];
+    __shared__ int32_t lvals[LT];
     constexpr int GPB = THREADS / G;
     const int tid = threadIdx.x;
     const int gl = tid & (G - 1);
@@ -77,6 +76,7 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
     const int r = blockIdx.x * GPB + tid / G;
     if (FRONTIER) {
         if (tid == 0) blk[0] = 0;
+        for (int e = tid; e < LT; e += THREADS) lkeys[e] = -1;
         __syncthreads();
     }
     int nn = n;
@@ -117,26 +117,7 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
             c = (int)min(deg, (int64_t)k);
         }
         const bool floyd = active && deg > (int64_t)k;
-        uint32_t pos = (uint32_t)gl;        // deg <= k: the whole row, in CSR order
-        if (__any(floyd)) {
-            // Floyd: a uniform k-subset of positions [0, deg).  Step i draws t_i in [0, deg-k+i]
-            // and takes it unless one of the i earlier picks already is t_i, then takes deg-k+i.
-            const uint32_t ji = (uint32_t)(deg - (int64_t)k) + (uint32_t)gl;
-            uint32_t ti = 0;
-            if (floyd && gl < k) {
-                const uint32_t t_ = (r < tag_self_rows) ? tag_self : tag;
-                const Philox4 p = philox4x32_10((uint32_t)v, t_, (uint32_t)(gl >> 2), 0u, key0, key1);
-                ti = sage_bounded(philox_word(p, gl & 3), ji + 1u);
-            }
-            uint32_t chosen = ti;
-            for (int i = 1; i < k; ++i) {
-                const uint32_t t = (uint32_t)__shfl((int)ti, i, G);
-                const unsigned long long b = __ballot(floyd && gl < i && chosen == t);
-                const unsigned long long gb = (G == kWave) ? b : ((b >> (lane - gl)) & ((1ull << (G & 63)) - 1ull));
-                if (gl == i) chosen = gb ? ji : ti;
-            }
-            if (floyd) pos = chosen;
-        }
+        const uint32_t pos = sage_group_positions<G>(floyd, deg, k, v, (r < tag_self_rows) ? tag_self : tag, key0, key1, gl, lane);
         if (active) {
             if (gl < c) id = col[s + (int64_t)pos];
             if (gl < k) nbr[(int64_t)r * k + gl] = id;
@@ -144,7 +125,10 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
         }
     } else {
         if (active) {
-            v = nodes ? nodes[r] : -1;
+            if (nodes && (insert_self || bs.nodes_copy)) {
+                v = nodes[r];
+                if (bs.nodes_copy && gl == 0) bs.nodes_copy[r] = v;
+            }
             c = min(in_cnt[r], k);
             if (gl < c) id = in_nbr[(int64_t)r * k + gl];
         }
@@ -157,10 +141,31 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
             __hip_atomic_store(any_nonempty, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (FRONTIER) {
-        bool won = false, selfwon = false;
-        int slot = -1, sslot = -1;
-        if (active && gl < c) slot = sage_hash_insert(f.keys, f.mask, id, won);
-        if (active && insert_self && gl == 0) sslot = sage_hash_insert(f.keys, f.mask, v, selfwon);
+        // Two-level insert.  A hub id occurs ~1000 times among the 10^5 ids of a batch; 1000 CAS on one global word
+        // serialise at ~12 ns each (the insert took 11-28 us depending on the batch's hubs).  Each block therefore
+        // dedupes its own <= THREADS + THREADS/G ids in an LDS hash first (LDS atomics are cheap), only the block's
+        // first occurrence of an id goes to the global table, and the others read the slot it got.
+        constexpr uint32_t LMASK = LT - 1;
+        auto lds_insert = [&](int32_t key, bool& first) -> int {
+            uint32_t ls = sage_hash_slot((uint32_t)key, LMASK);
+            first = false;
+            for (uint32_t probe = 0; probe <= LMASK; ++probe) {
+                const int32_t seen = atomicCAS(&lkeys[ls], -1, key);
+                if (seen == -1) { first = true; return (int)ls; }
+                if (seen == key) return (int)ls;
+                ls = (ls + 1) & LMASK;
+            }
+            return -1;
+        };
+        bool won = false, selfwon = false, lfirst = false, sfirst = false;
+        int slot = -1, sslot = -1, ls = -1, sls = -1;
+        if (active && gl < c) ls = lds_insert(id, lfirst);
+        if (active && insert_self && gl == 0) sls = lds_insert(v, sfirst);
+        if (lfirst) { slot = sage_hash_insert(f.keys, f.mask, id, won); lvals[ls] = slot; }
+        if (sfirst) { sslot = sage_hash_insert(f.keys, f.mask, v, selfwon); lvals[sls] = sslot; }
+        __syncthreads();
+        if (ls >= 0 && !lfirst) slot = lvals[ls];
+        if (sls >= 0 && !sfirst) sslot = lvals[sls];
         if (active) {
             if (gl < k) nbr_slot[(int64_t)r * k + gl] = slot;
             if (insert_self && gl == 0) self_slot[r] = sslot;

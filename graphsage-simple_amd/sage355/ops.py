@@ -77,7 +77,7 @@ class Frontier:
 
 
 def sample_neighbors(rowptr, col, nodes, k, seed, tag=TAG_OUTER, n_dev=None, frontier=None, insert_self=False,
-                     any_nonempty=None):
+                     any_nonempty=None, out_nbr=None, out_cnt=None):
     """encoders.py:47 + aggregators.py:42-48 (+52-53 with a frontier).
     -> (nbr int32 [n,k], cnt int32 [n], nbr_slot or None, self_slot or None)."""
     _need_gpu()
@@ -86,8 +86,10 @@ def sample_neighbors(rowptr, col, nodes, k, seed, tag=TAG_OUTER, n_dev=None, fro
     _chk(nodes, torch.int32, "nodes", 1)
     n = nodes.shape[0]
     dev = nodes.device
-    nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
-    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    nbr = torch.empty((n, k), dtype=torch.int32, device=dev) if out_nbr is None else _chk(out_nbr, torch.int32, "out_nbr")
+    cnt = torch.empty(n, dtype=torch.int32, device=dev) if out_cnt is None else _chk(out_cnt, torch.int32, "out_cnt")
+    if nbr.numel() < n * k or cnt.numel() < n:
+        raise native.SageError("sample_neighbors: output buffers too small")
     nbr_slot = torch.empty((n, k), dtype=torch.int32, device=dev) if frontier is not None else None
     self_slot = torch.empty(n, dtype=torch.int32, device=dev) if (frontier is not None and insert_self) else None
     rc = native.lib().sage_sample_neighbors(

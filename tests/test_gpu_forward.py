@@ -215,22 +215,29 @@ def test_graph_replay_of_queued_batches_equals_direct_calls():
     rowptr, col = graph.to(DEV)
     deg = graph.degrees()
     rs = np.random.default_rng(5)
-    seeds = torch.from_numpy(np.stack([rs.choice(np.nonzero(deg > 0)[0], 512, replace=False) for _ in range(5)]).astype(np.int32)).to(DEV)
+    # 600 seeds x fanout 25 -> layer 1 is large enough to take the split (column-sliced gather + dense contraction) path
+    seeds = torch.from_numpy(np.stack([rs.choice(np.nonzero(deg > 0)[0], 600, replace=False) for _ in range(5)]).astype(np.int32)).to(DEV)
     keys = [11, 2**63 + 5, 13, 2**64 - 1, 17]
     for concat in (False, True):
         m = 2 if concat else 1
         w1c = w1.repeat(1, m).contiguous()
         w2c = w2.repeat(1, m).contiguous()
-        direct = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=512)
+        direct = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=600)
         want = [direct.forward(seeds[i], seed=keys[i]).clone() for i in range(5)]
-        eng = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=512)
+        eng = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=600)
         eng.set_queue(seeds, keys)
         out = eng.capture()
+        assert eng.layout.layer1_split == 1
         for rnd in range(2):                       # second round: the ring wraps around
             for i in range(5):
                 eng.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(out, want[i]), f"concat={concat} round {rnd} batch {i}"
+        eng.rewind(3)                              # jump inside the ring
+        for i in (3, 4, 0):
+            eng.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want[i]), f"concat={concat} after rewind, batch {i}"
 
 
 def test_integration_md_ctypes_stub():
