@@ -272,146 +272,6 @@ int launch(const FusedArgs& a, hipStream_t st) {
     return SAGE_OK;
 }
 
-// ---- small, narrow layers (layer 2: a few thousand rows of <= 128 columns) -----------------------------------
-// Latency bound, so the kernel is organised around the number of DEPENDENT round trips, not bytes:
-//   trip 1  every lane group loads its row's count AND its k neighbour ids together (ids beyond the count
-//           are padding and are masked afterwards), while the whole block copies W into LDS;
-//   trip 2  all neighbour rows of the pass are requested at once (NF wave-instructions in flight);
-//   then    mean -> LDS tile -> barrier -> MFMA with K split over ALL 16 waves (4 column slices x 4 K quarters,
-//           partial sums combined through LDS) -> act -> store.
-// One M-row tile per block of WAVES waves (M = 16 x 8 waves when that is what it takes to put a block on every CU:
-// 4096 rows -> 256 blocks; the MFMA tile stays 32 rows, its upper half unused); LG = KP/4 lanes cover a row, so a
-// wave gathers 64/LG rows per pass.
-template <int KP, int NF, int M, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void layer_small_kernel(const FusedArgs a) {
-    constexpr int LDA = KP + 4;
-    constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES;      // RPW = 2
-    constexpr int PASSES = (RPW + RPP - 1) / RPP;                   // 1
-    constexpr int KSPLIT = WAVES / 4;                               // wave groups along K in the MFMA phase
-    constexpr int KQ = KP / KSPLIT;                                 // K columns per wave
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // A [32][LDA] | W [128][LDA] | partials [(KSPLIT-1)*4][16][64]
-    float* wl = lds + 32 * LDA;
-    float* red = wl + 128 * LDA;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int nn = a.n;
-    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
-    const int row0 = blockIdx.x * M;
-    if (row0 < nn) {
-        const bool nan_rule = a.any_nonempty ? (*a.any_nonempty != 0) : false;
-        const int last_row = a.table_rows - 1;
-        const int lg = lane & (LG - 1), sg = lane / LG;
-        const int c0 = lg * 4;
-        const bool col_ok = c0 < a.dim;
-        // W -> LDS (zero padded to [128][KP]); in flight together with trip 1
-        for (int e = tid; e < 128 * (KP / 4); e += WAVES * 64) {
-            const int wr = e / (KP / 4), wc = (e % (KP / 4)) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (wr < a.out_dim && wc < a.dim) v = *reinterpret_cast<const f32x4*>(a.W + (int64_t)wr * a.ldw + wc);
-            *reinterpret_cast<f32x4*>(wl + wr * LDA + wc) = v;
-        }
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int rsub = p * RPP + sg;
-            const int r = wave * RPW + rsub;
-            const int g = row0 + r;
-            const bool valid = rsub < RPW && g < nn;
-            const int gq = valid ? g : 0;
-            // trip 1
-            int c = valid ? a.cnt[gq] : 0;
-            int myid = (valid && lg < a.k) ? a.nbr[(int64_t)gq * a.k + lg] : -1;
-            int s = (valid && a.self_row) ? a.self_row[gq] : -1;
-            c = min(c, LG);
-            if (lg >= c) myid = -1;
-            if (a.slot_rows) {
-                if (myid >= 0) myid = a.slot_rows[myid];
-                if (s >= 0) s = a.slot_rows[s];
-            }
-            bool extra = s >= 0;
-            const unsigned long long hit = __ballot(extra && myid >= 0 && myid == s);
-            if ((hit >> (lane - lg)) & ((1ull << LG) - 1ull)) extra = false;      // aggregators.py:50-51: set union
-            myid = min(max(myid, 0), last_row);
-            // trip 2
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int j0 = 0; __any(j0 < c); j0 += NF) {
-                f32x4 t[NF];
-#pragma unroll
-                for (int u = 0; u < NF; ++u) {
-                    const int j = j0 + u;
-                    const int id = __shfl(myid, min(j, LG - 1), LG);
-                    t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (col_ok && j < c) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
-                }
-#pragma unroll
-                for (int u = 0; u < NF; ++u) acc += t[u];
-            }
-            if (extra && col_ok) acc += *reinterpret_cast<const f32x4*>(a.table + (int64_t)min(s, last_row) * a.ld + c0);
-            const int ceff = c + (extra ? 1 : 0);
-            f32x4 mean;
-            if (ceff > 0) mean = acc * (1.0f / (float)ceff);
-            else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
-            if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rsub < RPW) *reinterpret_cast<f32x4*>(lds + r * LDA + c0) = valid ? mean : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();
-        // MFMA: wave (ns = w & 3, kq = w >> 2) contracts K quarter kq for output columns [32 ns, 32 ns + 32)
-        const int i32 = lane & 31, h = lane >> 5;
-        const int ns = wave & 3, kq = wave >> 2;
-        f32x16 accm;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accm[e] = 0.f;
-        const float* ab = lds + i32 * LDA + kq * KQ + 4 * h;
-        const float* wb = wl + (ns * 32 + i32) * LDA + kq * KQ + 4 * h;
-#pragma unroll
-        for (int q = 0; q < KQ / 8; ++q) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(ab + 8 * q);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + 8 * q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], accm, 0, 0, 0);
-        }
-        if (kq > 0) {
-            float* dst = red + ((kq - 1) * 4 + ns) * 16 * 64;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dst[e * 64 + lane] = accm[e];
-        }
-        __syncthreads();
-        if (kq == 0) {
-#pragma unroll
-            for (int qq = 0; qq < KSPLIT - 1; ++qq) {
-                const float* src = red + (qq * 4 + ns) * 16 * 64;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) accm[e] += src[e * 64 + lane];
-            }
-            const int col = ns * 32 + i32;
-            if (col < a.out_dim) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rt = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    const int g = row0 + rt;
-                    if (rt < M && g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(accm[reg], a.act);
-                }
-            }
-        }
-    }
-    sage_finish_block(a.fin, (int)gridDim.x);
-}
-
-template <int KP, int NF, int M, int WAVES>
-int launch_small(const FusedArgs& a, hipStream_t st) {
-    constexpr size_t lds = ((size_t)(32 + 128) * (KP + 4) + (WAVES / 4 - 1) * 4 * 16 * 64) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute((const void*)layer_small_kernel<KP, NF, M, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            sage_set_error("layer_forward: cannot reserve %zu bytes of LDS", lds);
-            return SAGE_ELAUNCH;
-        }
-        configured = true;
-    }
-    hipLaunchKernelGGL((layer_small_kernel<KP, NF, M, WAVES>), dim3(sage_cdiv(a.n, M)), dim3(WAVES * 64), lds, st, a);
-    SAGE_CHECK_LAUNCH("layer_small_kernel");
-    return SAGE_OK;
-}
-
 // Tile shape by layer size (measured on MI355X, config-3 layer 1, 23.5k rows x 256 -> 128):
 //   64-row tiles, W slice in VGPRs, 2 blocks/CU ............ 82 us
 //   32-row tiles, W slice in VGPRs, 2 blocks/CU ............ 80 us
@@ -429,12 +289,10 @@ int launch_by_rows(const FusedArgs& a, hipStream_t st) {
         else if constexpr (KP == 256) return launch<KP, 32, 4, false, CONCAT>(a, st);
         else return launch<KP, 64, 4, true, CONCAT>(a, st);
     }
-    if constexpr (KP <= 128 && !CONCAT) {
-        if (a.k <= KP / 4) {                                                                      // ids fit one lane group: 2-trip kernel
-            return launch_small<KP, 16, 32, 16>(a, st);   // (16-row tiles x 8 waves, a block on every CU, measured slower: 18.2 vs 14.8 us)
-        }
-        return launch<KP, 32, 16, true, CONCAT, 6>(a, st);    // 6 in flight: stays inside the 128-VGPR budget of a 16-wave block
-    }
+    // (A dedicated 2-trip kernel for this case -- ids+counts in one load, all rows in flight, W through LDS, 133 KB of
+    // LDS per 1024-thread block -- ran 1 us faster alone and 7 % SLOWER with a second batch in flight: its footprint
+    // keeps other kernels off the CU.  What shares the chip well beats what is fastest alone.)
+    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, 16, true, CONCAT, 6>(a, st);    // 6 in flight: inside the 128-VGPR budget of a 16-wave block
     else return launch<KP, 32, 8, true, CONCAT>(a, st);
 }
 

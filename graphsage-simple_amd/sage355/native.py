@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsage355.so")
+LIB_PATH = os.environ.get("SAGE355_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libsage355.so")   # env: A/B another build
 CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 
 ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
