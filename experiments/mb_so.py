@@ -8,7 +8,7 @@ dev = "cuda"
 g = rmat_graph(20, 16_000_000, cache_dir="/tmp/sage_cache")
 table = torch.randn(g.num_nodes, 256, device=dev)
 rowptr, col = g.to(dev)
-eng = TwoHopEngine(rowptr, col, table, torch.randn(128, 256, device=dev) / 16, torch.randn(128, 128, device=dev) / 11, 15, 25, max_batch=4096)
+eng = TwoHopEngine(rowptr, col, table, torch.randn(128, 256, device=dev) / 16, torch.randn(128, 128, device=dev) / 11, 15, 25, max_batch=4096, nan_empty=os.environ.get('SAGE_NAN', '1') == '1')
 deg = g.degrees(); cands = np.nonzero(deg > 0)[0]
 S = 40
 seeds = torch.from_numpy(np.stack([np.random.default_rng(i).choice(cands, 4096, replace=False) for i in range(S)]).astype(np.int32)).to(dev)

@@ -167,7 +167,10 @@ int launch(const DenseArgs& a, hipStream_t st) {
     }
     // one persistent block per CU (24.9 us) beat two (26.3 us) on the config-3 contraction: the prefetch only pays
     // when a block owns >= 2 tiles, and one block per CU leaves wave slots for another batch's kernels
-    const int grid = min(sage_cdiv(a.n, 32), kNumCU);
+#ifndef SAGE_DENSE_PER_CU
+#define SAGE_DENSE_PER_CU 1
+#endif
+    const int grid = min(sage_cdiv(a.n, 32), SAGE_DENSE_PER_CU * kNumCU);
     hipLaunchKernelGGL((dense_layer_kernel<KP, CONCAT>), dim3(grid), dim3(KSPLIT ? 512 : 256), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_layer_kernel");
     return SAGE_OK;

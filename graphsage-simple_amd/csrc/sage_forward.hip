@@ -127,7 +127,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     const int64_t ldw1 = (int64_t)m->d0 * (m->concat ? 2 : 1);
     const int64_t ldw2 = (int64_t)m->h1 * (m->concat ? 2 : 1);
     const int32_t* nan1 = m->nan_empty ? any1 : nullptr;
-    const int32_t* nan2 = m->nan_empty ? any2 : nullptr;
+    // outer hop: some neighbour was sampled  <=>  the frontier counter is non-zero, so layer 2 needs no flag at all
+    const int32_t* nan2 = m->nan_empty ? (self_loop ? any2 : s1_count) : nullptr;
     const bool fuse1 = m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 &&
                        sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
     // wide + large layer 1: column-sliced gather (cross-XCD L2 partitioning) into agg1, then a dense contraction;
@@ -137,7 +138,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
-                                    cnt2, any2, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
+                                    cnt2, (m->nan_empty && self_loop) ? any2 : nullptr, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
                                     nullptr, st))
         return rc;
     SAGE_EV(1);
@@ -148,7 +149,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     const sage_resolve_t resolve{slot2, row2, batch * m->k2, self_loop ? self_slot2 : nullptr, self_row2, batch, fr.rows, fr.keys};
     SAGE_EV(2);
     if (int rc = sage_launch_sample(m->rowptr1, m->col1, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
-                                    SAGE_TAG_INNER_SELF, nbr1, cnt1, any1, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
+                                    SAGE_TAG_INNER_SELF, nbr1, cnt1, m->nan_empty ? any1 : nullptr, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
                                     &resolve, st))
         return rc;
     SAGE_EV(3);

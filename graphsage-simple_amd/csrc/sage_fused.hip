@@ -292,7 +292,10 @@ int launch_by_rows(const FusedArgs& a, hipStream_t st) {
     // (A dedicated 2-trip kernel for this case -- ids+counts in one load, all rows in flight, W through LDS, 133 KB of
     // LDS per 1024-thread block -- ran 1 us faster alone and 7 % SLOWER with a second batch in flight: its footprint
     // keeps other kernels off the CU.  What shares the chip well beats what is fastest alone.)
-    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, 16, true, CONCAT, 6>(a, st);    // 6 in flight: inside the 128-VGPR budget of a 16-wave block
+#ifndef SAGE_L2_WAVES
+#define SAGE_L2_WAVES 16
+#endif
+    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, SAGE_L2_WAVES, true, CONCAT, 6>(a, st);    // 6 in flight: inside the 128-VGPR budget of a 16-wave block
     else return launch<KP, 32, 8, true, CONCAT>(a, st);
 }
 

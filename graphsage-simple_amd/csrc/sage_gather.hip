@@ -180,7 +180,10 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
     if (n == 0) return SAGE_OK;
     if (sage_gather_is_sliced(dim, ld, ldo, table, out, n, k)) {
         const int nslice = sage_cdiv(dim, 64);                   // 256-B slices
-        const int blocks = nslice * (kNumCU * 8 / nslice);
+#ifndef SAGE_G_PER_CU
+#define SAGE_G_PER_CU 8
+#endif
+        const int blocks = nslice * (kNumCU * SAGE_G_PER_CU / nslice);
         hipLaunchKernelGGL(gather_mean_sliced_kernel<16>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
                            n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
         SAGE_CHECK_LAUNCH("gather_mean_sliced_kernel");

@@ -134,11 +134,16 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
         }
     }
     if (any_nonempty) {
-        // every wave used to atomicOr this one word: 6000 same-address atomics = 67 us (~88/us).
-        // All writers store the same value, so a plain (agent-scope, L1-bypassing) check + store does.
-        if (__any(c > 0) && lane == 0 &&
-            __hip_atomic_load(any_nonempty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            __hip_atomic_store(any_nonempty, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ONE flag word for the whole launch, so it must not be touched per wave: 6000 waves each doing an atomicOr
+        // on it cost 67 us, and even an L1-bypassing load + store per wave cost 27 us per forward (same-address
+        // requests queue in one L2 channel).  The block ORs its waves in LDS and thread 0 alone looks at the word
+        // (plain, L1-cacheable load) and writes it if it still reads 0.
+        __shared__ int blk_any;
+        if (tid == 0) blk_any = 0;
+        __syncthreads();
+        if (__any(c > 0) && lane == 0) blk_any = 1;
+        __syncthreads();
+        if (tid == 0 && blk_any && *any_nonempty == 0) *any_nonempty = 1;
     }
     if constexpr (FRONTIER) {
         // Two-level insert.  A hub id occurs ~1000 times among the 10^5 ids of a batch; 1000 CAS on one global word
@@ -228,7 +233,10 @@ template <bool SAMPLE, bool FRONTIER, typename... A>
 void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
     // frontier variants use 1024-thread blocks: one global counter atomic per 1024/G nodes (256- and 512-thread
     // blocks were measured 3-5 % slower end to end)
-    if constexpr (FRONTIER) launch_by_fanout_t<1024, SAMPLE, FRONTIER>(k, n, st, args...);
+#ifndef SAGE_SO_THREADS
+#define SAGE_SO_THREADS 1024
+#endif
+    if constexpr (FRONTIER) launch_by_fanout_t<SAGE_SO_THREADS, SAMPLE, FRONTIER>(k, n, st, args...);
     else launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, n, st, args...);
 }
 
