@@ -242,6 +242,12 @@ def main():
     # ---- dominant kernel (layer 1) duration: the same K steps again, same streams in flight, host-enqueued with HIP
     #      events on the kernel's own stream; the data-determined set sizes of every batch are counted in the same
     #      pass by torch reductions enqueued behind each forward (no host sync inside the pass) ----
+    workload = (f"BASELINE configs[{args.config - 1}]: "
+                + ("Pubmed topology (19717 nodes)" if args.config == 2 else
+                   f"R-MAT 2^{args.scale} / {args.edges} edges" + (f" truncated to {n} nodes" if args.truncate else f" ({n} nodes)"))
+                + f", {graph.nnz} directed nnz, {d0}-dim fp32 features, 2-layer GraphSAGE-mean {args.mode} encoder"
+                + (" + self-loop (GCN-variant) aggregator" if args.self_loop else "")
+                + f" H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU")
     roofline = None
     if rank == 0:
         he = HipEvents()
@@ -305,7 +311,9 @@ def main():
         tfile = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("layer1_hbm_bytes_per_launch")
+                tj = json.load(open(tfile))          # PMC passes are separate runs (profiles/collect.sh): only valid
+                if tj.get("workload", workload) == workload and split:     # for the workload they were collected on
+                    traffic = tj.get("layer1_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         achieved = l1 / (layer1_ms * 1e-3) / 1e9
@@ -334,12 +342,7 @@ def main():
             "metric": "node-embeddings/sec (2-hop forward)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: " + (
-                           "Pubmed topology (19717 nodes)" if args.config == 2 else
-                           f"R-MAT 2^{args.scale} / {args.edges} edges" + (f" truncated to {n} nodes" if args.truncate else f" ({n} nodes)"))
-                           + f", {graph.nnz} directed nnz, {d0}-dim fp32 features, 2-layer GraphSAGE-mean {args.mode} encoder"
-                           + (" + self-loop (GCN-variant) aggregator" if args.self_loop else "")
-                           + f" H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU",
+            "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
                        "streams_in_flight": nstreams, "fused_layers": not args.unfused, "hip_graph_replay": use_graph,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
     float* __restrict__ out, int64_t ldo, int n_off, int nslice) {
     using V = __attribute__((ext_vector_type(4))) float;
     constexpr int NPI = kWave / SL;             // neighbours per wave-instruction
-    constexpr int U = 4;                        // wave-instructions in flight
+#ifndef SAGE_G_INFLIGHT
+#define SAGE_G_INFLIGHT 4
+#endif
+    constexpr int U = SAGE_G_INFLIGHT;          // wave-instructions in flight
     int nn = n;
     if (n_dev) nn = min(*n_dev + n_off, n);
     const int lane = sage_lane();
@@ -179,12 +182,15 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
                             hipStream_t st) {
     if (n == 0) return SAGE_OK;
     if (sage_gather_is_sliced(dim, ld, ldo, table, out, n, k)) {
-        const int nslice = sage_cdiv(dim, 64);                   // 256-B slices
 #ifndef SAGE_G_PER_CU
 #define SAGE_G_PER_CU 8
 #endif
+#ifndef SAGE_SLICE_LANES
+#define SAGE_SLICE_LANES 16                                       // 256-B slices
+#endif
+        const int nslice = sage_cdiv(dim, SAGE_SLICE_LANES * 4);
         const int blocks = nslice * (kNumCU * SAGE_G_PER_CU / nslice);
-        hipLaunchKernelGGL(gather_mean_sliced_kernel<16>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
+        hipLaunchKernelGGL(gather_mean_sliced_kernel<SAGE_SLICE_LANES>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
                            n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
         SAGE_CHECK_LAUNCH("gather_mean_sliced_kernel");
         return SAGE_OK;
