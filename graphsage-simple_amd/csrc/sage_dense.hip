@@ -176,6 +176,211 @@ int launch(const DenseArgs& a, hipStream_t st) {
     return SAGE_OK;
 }
 
+// ---- the same contraction on the bf16 matrix pipe, fp32-accurate (split operands) ----------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (1/16 of bf16 MFMA), and with it this kernel spends ~8200
+// matrix-pipe cycles per 32-row tile.  An fp32 value is exactly hi + mid + lo with three bf16 terms (8 + 8 + 8
+// significant bits, round-to-nearest each time, the remainders are exact in fp32), and a bf16 x bf16 product is exact
+// in the MFMA's fp32 accumulator, so
+//     x * w  =  hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)  +  O(2^-24 |x||w|)
+// -- six v_mfma_f32_32x32x16_bf16 (32 cycles each for 16 k) per k-step instead of eight 64-cycle fp32 MFMAs:
+// 192 vs 512 cycles, with an error of the order of the fp32 rounding the reference's sgemm makes anyway (the 1e-5
+// parity gate is relative to the row maximum; measured max error 1e-6, tests/test_gpu_ops.py, bench.py parity gate).
+// Structure: 8 waves per block; wave w owns output columns [32(w&3), +32) of K half (w>>2); its W slice is split once,
+// at kernel start, into three bf16 planes that stay in VGPRs (96 at K = 256).  A tile's rows are split once by the
+// threads that stage them (v_cvt_pk_bf16_f32 / v_pk_add_f32, ~5 VALU per element) into three bf16 LDS planes whose rows
+// are padded by 16 B, so an A operand is ONE ds_read_b128.  The two K halves meet through LDS.  Double-buffered tiles,
+// next tile's rows in flight during the MFMA loop, as above.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x8 = __attribute__((ext_vector_type(8))) float;
+
+__device__ inline void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+    hi = __builtin_convertvector(x, bf16x4);
+    const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
+    mid = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+    lo = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int KP, bool CONCAT>
+__global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
+    constexpr int M = 32, WAVES = 8;
+    constexpr int CHUNKS = CONCAT ? 2 : 1;
+    constexpr int KTOT = CHUNKS * KP, KH = KTOT / 2, STEPS = KH / 16;
+    constexpr int LDB = KTOT + 8;                        // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
+    constexpr int PL = M * LDB;                          // elements per plane
+    constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
+    static_assert(RPW % RPP == 0 && KH % 16 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);                                   // [2][3][M][LDB]
+    float* red = reinterpret_cast<float*>(lds_raw + (size_t)2 * 3 * PL * sizeof(__bf16));  // [4][16][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nn = a.n;
+    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
+    const int ntiles = (nn + M - 1) / M;
+    if ((int)blockIdx.x < ntiles) {
+        const bool nan_rule = (a.cnt && a.any_nonempty) ? (*a.any_nonempty != 0) : false;
+        const int i32 = lane & 31, h = lane >> 5;
+        const int n0 = (wave & 3) * 32;
+        const int kgroup = wave >> 2;
+        const bool mfma_wave = n0 < a.out_dim;
+        const int lg = lane & (LG - 1), sg = lane / LG;
+        const int c0 = lg * 4;
+        const bool col_ok = c0 < a.dim;
+
+        // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = kgroup*KH + 16 st + 8 h in the
+        // [self | agg] K index space (chunk kk / KP, column kk % KP).  W goes through LDS: read straight from global,
+        // lane i of a wave sits on row n0+i -- 64 different cache lines per load instruction, 1 MB of L1 line traffic
+        // per block for 128 KB of weights (that, not the matrix pipe, was 8 us of the fp32 kernel's 25).  So all 512
+        // threads fetch the [128, KTOT] weights row-contiguously (16 B per lane, one trip), park 64 rows at a time in
+        // the tile buffers, and each wave picks its operand fragments up with conflict-free ds_read_b128.
+        bf16x8 bw[STEPS][3];
+        {
+            constexpr int LW = KTOT / 4, RPPW = 512 / LW, WPASS = 128 / RPPW, LDW = KTOT + 4;
+            static_assert(64 % RPPW == 0 && (size_t)64 * LDW * 4 <= (size_t)2 * 3 * PL * 2, "W staging fits the tile buffers");
+            float* wst = reinterpret_cast<float*>(lds_raw);
+            const int wl = tid % LW, wr = tid / LW;
+            const int wchunk = (4 * wl) / KP, wcol = (4 * wl) % KP;
+            f32x4 wv[WPASS];
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) {
+                const int row = p * RPPW + wr;
+                wv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < a.out_dim && wcol < a.dim) wv[p] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)row * a.ldw + (int64_t)wchunk * a.dim + wcol);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int p = half * (WPASS / 2); p < (half + 1) * (WPASS / 2); ++p)
+                    *reinterpret_cast<f32x4*>(wst + (p * RPPW + wr - 64 * half) * LDW + 4 * wl) = wv[p];
+                __syncthreads();
+                if (((wave & 3) >> 1) == half) {
+                    const float* src = wst + ((wave & 1) * 32 + i32) * LDW + kgroup * KH + 8 * h;
+#pragma unroll
+                    for (int st = 0; st < STEPS; ++st) {
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * st);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * st + 4);
+                        bf16x4 h0, m0, l0, h1, m1, l1;
+                        split3(v0, h0, m0, l0);
+                        split3(v1, h1, m1, l1);
+                        bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        f32x4 xr[PASSES], sr[CONCAT ? PASSES : 1];
+        auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int g = tile * M + wave * RPW + p * RPP + sg;
+                const bool valid = g < nn && col_ok;
+                xr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (valid) {
+                    xr[p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
+                    if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[p] = f32x4{q, q, q, q}; }
+                }
+                if (CONCAT) {
+                    sr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (valid) {
+                        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1)
+                                                       : (int64_t)min(g, a.self_rows - 1);
+                        sr[p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + c0);
+                    }
+                }
+            }
+        };
+        auto stage_tile = [&](__bf16* buf) {                  // VGPRs -> split -> three bf16 LDS planes
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int r = wave * RPW + p * RPP + sg;
+                bf16x4 hi, mid, lo;
+                split3(xr[p], hi, mid, lo);
+                __bf16* dst = buf + r * LDB + (CHUNKS - 1) * KP + c0;
+                *reinterpret_cast<bf16x4*>(dst) = hi;
+                *reinterpret_cast<bf16x4*>(dst + PL) = mid;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PL) = lo;
+                if (CONCAT) {
+                    split3(sr[p], hi, mid, lo);
+                    __bf16* ds = buf + r * LDB + c0;
+                    *reinterpret_cast<bf16x4*>(ds) = hi;
+                    *reinterpret_cast<bf16x4*>(ds + PL) = mid;
+                    *reinterpret_cast<bf16x4*>(ds + 2 * PL) = lo;
+                }
+            }
+        };
+
+        int tile = blockIdx.x, b = 0;
+        request_tile(tile);
+        for (; tile < ntiles; tile += gridDim.x, b ^= 1) {
+            __bf16* buf = lds + b * 3 * PL;
+            stage_tile(buf);
+            __syncthreads();
+            const int next = tile + gridDim.x;
+            if (next < ntiles) request_tile(next);            // in flight during the MFMA loop below
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            if (mfma_wave) {
+                const __bf16* abase = buf + i32 * LDB + kgroup * KH + 8 * h;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(abase + 16 * st);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(abase + PL + 16 * st);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(abase + 2 * PL + 16 * st);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw[st][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], acc, 0, 0, 0);
+                }
+            }
+            float* myred = red + (wave & 3) * 16 * 64;        // K half 1 -> LDS -> K half 0
+            if (kgroup == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) myred[e * 64 + lane] = acc[e];
+            }
+            __syncthreads();
+            if (kgroup == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] += myred[e * 64 + lane];
+                const int col = n0 + i32;
+                if (mfma_wave && col < a.out_dim) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[reg], a.act);
+                    }
+                }
+            }
+        }
+    }
+    sage_finish_block(a.fin, (int)gridDim.x);
+}
+
+template <int KP, bool CONCAT>
+int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 3 * 32 * ((CONCAT ? 2 : 1) * KP + 8) * 2 + (size_t)4 * 16 * 64 * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds) != hipSuccess) {
+            sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
+            return SAGE_ELAUNCH;
+        }
+        configured = true;
+    }
+    const int grid = min(sage_cdiv(a.n, 32), kNumCU);
+    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT>), dim3(grid), dim3(512), lds, st, a);
+    SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
+    return SAGE_OK;
+}
+
 }  // namespace
 
 int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n, const int32_t* n_dev, int32_t concat,
@@ -192,6 +397,17 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     const DenseArgs a{x, ldx, dim, n, n_dev, n_off, concat ? self_tab : x, concat ? ld_self : ldx, concat ? (int)self_rows : n,
                       self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+#ifndef SAGE_DENSE_FP32
+    // split-bf16 contraction wherever a wave's W slice fits in <= 96 VGPRs (everything but the 512-deep concat layer)
+    if (!concat) {
+        if (kp == 64) return launch_bf16x3<64, false>(a, st);
+        if (kp == 128) return launch_bf16x3<128, false>(a, st);
+        return launch_bf16x3<256, false>(a, st);
+    }
+    if (kp == 64) return launch_bf16x3<64, true>(a, st);
+    if (kp == 128) return launch_bf16x3<128, true>(a, st);
+    return launch<256, true>(a, st);
+#else
     if (!concat) {
         if (kp == 64) return launch<64, false>(a, st);
         if (kp == 128) return launch<128, false>(a, st);
@@ -200,4 +416,5 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     if (kp == 64) return launch<64, true>(a, st);
     if (kp == 128) return launch<128, true>(a, st);
     return launch<256, true>(a, st);
+#endif
 }

@@ -251,6 +251,160 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
+// ---- small layers (layer 2 of the 2-hop forward: a few thousand destination rows) ---------------------------------
+// A layer this small is bound by (a) what ONE CU can pull through its L1 -- the 32-row tiles above put 4096 rows on
+// only 128 of the 256 CUs -- and (b) dependent round trips, each of which costs several microseconds while another
+// batch's gather is saturating the fabric (16 us alone became 40 us with a second batch in flight).
+// Here a tile is 16 rows (v_mfma_f32_16x16x4_f32), so 4096 rows fill all 256 CUs; a wave owns ONE row, its LG-lane
+// groups fetch different neighbours (the sliced gather's trick) with the whole neighbour list in flight, and the
+// groups meet in xor-shuffles: counts+ids -> rows -> LDS -> MFMA is two dependent trips instead of seven.
+// Waves 0..7 own the 16-column output tiles; their W slices are requested before the gather and stay in VGPRs.
+template <int KP, bool CONCAT, int INFLIGHT>
+__global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
+    constexpr int M = 16;
+    constexpr int CHUNKS = CONCAT ? 2 : 1;
+    constexpr int LDA = KP + 4;
+    constexpr int LG = KP / 4, NPI = 64 / LG;      // lanes per row, neighbours per wave-instruction
+    __shared__ __attribute__((aligned(16))) float lds[CHUNKS * M * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nn = a.n;
+    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
+    const int ntiles = (nn + M - 1) / M;
+    if ((int)blockIdx.x >= ntiles) {
+        sage_finish_block(a.fin, (int)gridDim.x);
+        return;
+    }
+    sage_finish_regs fin_regs;
+    sage_finish_begin(a.fin, fin_regs);
+    const bool nan_rule = a.any_nonempty ? (*a.any_nonempty != 0) : false;
+    const int last_row = a.table_rows - 1;
+    const int i16 = lane & 15, h = lane >> 4;
+    const int n0 = wave * 16;
+    const bool mfma_wave = n0 < a.out_dim;
+    const bool wrow_ok = mfma_wave && (n0 + i16) < a.out_dim;
+    const float* wrow = a.W + (int64_t)min(n0 + i16, a.out_dim - 1) * a.ldw;
+    // breg[chunk][4q+t] = W[n0+i][chunk*dim + 16q + 4h + t]: k-step 4q+t of the MFMA loop takes lane group h's
+    // k index from column 16q+4h+t (any pairing is valid as long as A and B agree; this one is 16-B contiguous per lane)
+    float breg[CHUNKS * (KP / 4)];
+#pragma unroll
+    for (int chunk = 0; chunk < CHUNKS; ++chunk)
+#pragma unroll
+        for (int q = 0; q < KP / 16; ++q) {
+            const int kc = 16 * q + 4 * h;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (wrow_ok && kc < a.dim) v = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) breg[chunk * (KP / 4) + 4 * q + t] = v[t];
+        }
+    const int lg = lane & (LG - 1), grp = lane / LG;
+    const int c0 = lg * 4;
+    const bool col_ok = c0 < a.dim;               // dim % 4 == 0 (host-checked); columns [dim, KP) are zero padding
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * M;
+        const int g = row0 + wave;
+        if (g < nn) {                              // wave-uniform; rows past nn are never stored
+            // the first 64 ids are requested together with the count (the list has a.k slots), not after it
+            int first_ids = (lane < a.k) ? a.nbr[(int64_t)g * a.k + lane] : 0;
+            const int c = __builtin_amdgcn_readfirstlane(a.cnt[g]);
+            int s = -1;
+            if (a.self_row) {
+                s = a.self_row[g];
+                if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+                s = __builtin_amdgcn_readfirstlane(s);
+            }
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+            if (CONCAT && grp == NPI - 1 && col_ok) {
+                const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+                sv = *reinterpret_cast<const f32x4*>(a.self_tab + sr * a.ld_self + c0);
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            bool extra = s >= 0;
+            for (int base = 0; base < c; base += kWave) {
+                const int m = min(kWave, c - base);
+                int myid = first_ids;
+                if (base > 0) myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
+                if (lane >= m) myid = 0;
+                if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                if (extra && __any(lane < m && myid == s)) extra = false;          // aggregators.py:50-51: set union
+                myid = min(max(myid, 0), last_row);
+                for (int j0 = 0; j0 < m; j0 += NPI * INFLIGHT) {
+                    f32x4 t[INFLIGHT];
+#pragma unroll
+                    for (int u = 0; u < INFLIGHT; ++u) {
+                        const int j = j0 + u * NPI + grp;
+                        const int id = __shfl(myid, min(j, m - 1), kWave);
+#ifdef SAGE_X_NOGATHER
+                        t[u] = f32x4{(float)id, 0.f, 0.f, 0.f};
+#else
+                        if (col_ok && j < m) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
+                        else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+                    }
+#pragma unroll
+                    for (int u = 0; u < INFLIGHT; ++u) acc += t[u];
+                }
+            }
+            if (extra && col_ok && grp == 0) acc += *reinterpret_cast<const f32x4*>(a.table + (int64_t)min(s, last_row) * a.ld + c0);
+#pragma unroll
+            for (int x = LG; x < kWave; x <<= 1) {
+                acc[0] += __shfl_xor(acc[0], x, kWave);
+                acc[1] += __shfl_xor(acc[1], x, kWave);
+                acc[2] += __shfl_xor(acc[2], x, kWave);
+                acc[3] += __shfl_xor(acc[3], x, kWave);
+            }
+            const int ceff = c + (extra ? 1 : 0);
+            f32x4 mean;
+            if (ceff > 0) mean = acc * (1.0f / (float)ceff);
+            else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
+            if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (grp == 0) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + wave) * LDA + c0) = mean;
+            if (CONCAT && grp == NPI - 1) *reinterpret_cast<f32x4*>(lds + wave * LDA + c0) = sv;
+        }
+        __syncthreads();
+        if (mfma_wave) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+                const float* abase = lds + (chunk * M + i16) * LDA + 4 * h;
+#pragma unroll
+                for (int q = 0; q < KP / 16; ++q) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(abase + 16 * q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#ifdef SAGE_X_NOMFMA
+                        acc[t] += av[t] * breg[chunk * (KP / 4) + 4 * q + t];
+#else
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], breg[chunk * (KP / 4) + 4 * q + t], acc, 0, 0, 0);
+#endif
+                }
+            }
+            const int col = n0 + i16;
+            if (col < a.out_dim) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gr = row0 + 4 * h + j;
+                    if (gr < nn) a.out[(int64_t)gr * a.ldo + col] = sage_activate(acc[j], a.act);
+                }
+            }
+        }
+        __syncthreads();     // the next tile's gather overwrites the LDS tile
+    }
+    sage_finish_block(a.fin, (int)gridDim.x, fin_regs);
+}
+
+template <int KP, bool CONCAT>
+int launch_tile16(const FusedArgs& a, hipStream_t st) {
+    // neighbour lists up to NPI x INFLIGHT entries are fetched in one trip: 26 (KP = 128) / 52 (KP = 64);
+    // the concat form keeps two W chunks in VGPRs and so has half the room for loads in flight
+    constexpr int INFLIGHT = CONCAT ? 7 : 13;
+    const int tiles = sage_cdiv(a.n, 16);
+    const int grid = min(tiles, 2 * kNumCU);
+    hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT>), dim3(grid), dim3(1024), 0, st, a);
+    SAGE_CHECK_LAUNCH("layer_tile16_kernel");
+    return SAGE_OK;
+}
+
 template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
 int launch(const FusedArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(CONCAT ? 2 : 1) * M * (KP + 4) * sizeof(float);
@@ -292,11 +446,13 @@ int launch_by_rows(const FusedArgs& a, hipStream_t st) {
     // (A dedicated 2-trip kernel for this case -- ids+counts in one load, all rows in flight, W through LDS, 133 KB of
     // LDS per 1024-thread block -- ran 1 us faster alone and 7 % SLOWER with a second batch in flight: its footprint
     // keeps other kernels off the CU.  What shares the chip well beats what is fastest alone.)
-#ifndef SAGE_L2_WAVES
-#define SAGE_L2_WAVES 16
-#endif
-    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, SAGE_L2_WAVES, true, CONCAT, 6>(a, st);    // 6 in flight: inside the 128-VGPR budget of a 16-wave block
+#ifdef SAGE_NO_TILE16
+    if constexpr (KP <= 128 && !CONCAT) return launch<KP, 32, 16, true, CONCAT, 6>(a, st);    // 6 in flight: inside the 128-VGPR budget of a 16-wave block
     else return launch<KP, 32, 8, true, CONCAT>(a, st);
+#else
+    if constexpr (KP <= 128) return launch_tile16<KP, CONCAT>(a, st);
+    else return launch<KP, 32, 8, true, CONCAT>(a, st);
+#endif
 }
 
 }  // namespace

@@ -175,7 +175,7 @@ def check_engine_against_oracle(graph, table, w1, w2, seeds, k1, k2, concat, sel
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("d0", [100, 256])      # 256: layer 1 takes the column-sliced gather + dense contraction
+@pytest.mark.parametrize("d0", [100, 128, 256])      # 128, 256: layer 1 takes the column-sliced gather + dense contraction
 @pytest.mark.parametrize("concat,self_loop", [(False, False), (True, False), (False, True), (True, True)])
 def test_two_hop_small_rmat_all_variants(concat, self_loop, fused, d0):
     graph = rmat_graph(14, 300_000, seed=2)
@@ -188,6 +188,28 @@ def test_two_hop_small_rmat_all_variants(concat, self_loop, fused, d0):
     deg = graph.degrees()
     seeds = np.random.default_rng(1).choice(np.nonzero(deg > 0)[0], 777, replace=False)
     check_engine_against_oracle(graph, table, w1, w2, seeds, 10, 20, concat, self_loop, fused)
+
+
+@pytest.mark.parametrize("d0", [128, 256])
+@pytest.mark.parametrize("concat", [False, True])
+def test_two_hop_isolated_seeds_take_the_nan_rule_through_the_split_layer(concat, d0):
+    """Seeds drawn from ALL nodes, isolated ones included: their rows are the reference's 0/0 = NaN
+    (aggregators.py:60-61) at layer 2 and, for the concat encoder, also at layer 1 (they head S1), where the
+    NaN has to survive the split-bf16 contraction of the dense kernel."""
+    graph = rmat_graph(14, 300_000, seed=2)
+    gen = torch.Generator().manual_seed(4)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, d0, generator=gen)
+    w1 = torch.randn(128, m * d0, generator=gen) / np.sqrt(m * d0)
+    w2 = torch.randn(64, m * 128, generator=gen) / np.sqrt(m * 128)
+    seeds = np.random.default_rng(3).choice(graph.num_nodes, 900, replace=False)
+    assert (graph.degrees()[seeds] == 0).sum() > 20
+    rowptr, col = torch.from_numpy(graph.rowptr).to(DEV), torch.from_numpy(graph.col).to(DEV)
+    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), 10, 20, concat=concat, max_batch=len(seeds))
+    out = eng.forward(torch.from_numpy(seeds.astype(np.int32)).to(DEV), seed=9).cpu()
+    assert eng.layout.layer1_split == 1
+    assert torch.isnan(out[torch.from_numpy(graph.degrees()[seeds] == 0)]).all()
+    check_engine_against_oracle(graph, table, w1, w2, seeds, 10, 20, concat, False, True, seed=9)
 
 
 @pytest.mark.parametrize("fused", [False, True])
