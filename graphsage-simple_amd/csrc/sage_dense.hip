@@ -229,50 +229,6 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const int c0 = lg * 4;
         const bool col_ok = c0 < a.dim;
 
-        // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = kgroup*KH + 16 st + 8 h in the
-        // [self | agg] K index space (chunk kk / KP, column kk % KP).  W goes through LDS: read straight from global,
-        // lane i of a wave sits on row n0+i -- 64 different cache lines per load instruction, 1 MB of L1 line traffic
-        // per block for 128 KB of weights (that, not the matrix pipe, was 8 us of the fp32 kernel's 25).  So all 512
-        // threads fetch the [128, KTOT] weights row-contiguously (16 B per lane, one trip), park 64 rows at a time in
-        // the tile buffers, and each wave picks its operand fragments up with conflict-free ds_read_b128.
-        bf16x8 bw[STEPS][3];
-        {
-            constexpr int LW = KTOT / 4, RPPW = 512 / LW, WPASS = 128 / RPPW, LDW = KTOT + 4;
-            static_assert(64 % RPPW == 0 && (size_t)64 * LDW * 4 <= (size_t)2 * 3 * PL * 2, "W staging fits the tile buffers");
-            float* wst = reinterpret_cast<float*>(lds_raw);
-            const int wl = tid % LW, wr = tid / LW;
-            const int wchunk = (4 * wl) / KP, wcol = (4 * wl) % KP;
-            f32x4 wv[WPASS];
-#pragma unroll
-            for (int p = 0; p < WPASS; ++p) {
-                const int row = p * RPPW + wr;
-                wv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < a.out_dim && wcol < a.dim) wv[p] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)row * a.ldw + (int64_t)wchunk * a.dim + wcol);
-            }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int p = half * (WPASS / 2); p < (half + 1) * (WPASS / 2); ++p)
-                    *reinterpret_cast<f32x4*>(wst + (p * RPPW + wr - 64 * half) * LDW + 4 * wl) = wv[p];
-                __syncthreads();
-                if (((wave & 3) >> 1) == half) {
-                    const float* src = wst + ((wave & 1) * 32 + i32) * LDW + kgroup * KH + 8 * h;
-#pragma unroll
-                    for (int st = 0; st < STEPS; ++st) {
-                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * st);
-                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 16 * st + 4);
-                        bf16x4 h0, m0, l0, h1, m1, l1;
-                        split3(v0, h0, m0, l0);
-                        split3(v1, h1, m1, l1);
-                        bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-
         f32x4 xr[PASSES], sr[CONCAT ? PASSES : 1];
         auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
 #pragma unroll
@@ -315,7 +271,30 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         };
 
         int tile = blockIdx.x, b = 0;
-        request_tile(tile);
+        request_tile(tile);                                   // the first tile's rows travel while W is fetched and split
+
+        // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = kgroup*KH + 16 st + 8 h in the
+        // [self | agg] K index space (chunk kk / KP, column kk % KP).  All loads of the slice are in flight at once.
+        // (Staging W through LDS with row-contiguous loads was measured: 23.1 vs 21.1 us -- the four extra barriers cost
+        // more than the uncoalesced but L2-resident 16-B loads.)
+        const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
+        const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
+        bf16x8 bw[STEPS][3];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int kk = kgroup * KH + 16 * st + 8 * h;
+            const int chunk = kk / KP, kc = kk % KP;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
+            if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc + 4);
+            bf16x4 h0, m0, l0, h1, m1, l1;
+            split3(v0, h0, m0, l0);
+            split3(v1, h1, m1, l1);
+            bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+
         for (; tile < ntiles; tile += gridDim.x, b ^= 1) {
             __bf16* buf = lds + b * 3 * PL;
             stage_tile(buf);
@@ -354,7 +333,12 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#ifndef SAGE_NO_NT_STORES   // streaming stores: the next kernel reads these rows from other XCDs anyway, and dirty lines left in L2 are
+                            // written back at the kernel boundary, on the critical path (gather 49.4 -> 48.3 us, contraction 22.2 -> 21.3)
+                        if (g < nn) __builtin_nontemporal_store(sage_activate(acc[reg], a.act), &a.out[(int64_t)g * a.ldo + col]);
+#else
                         if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[reg], a.act);
+#endif
                     }
                 }
             }
