@@ -206,8 +206,15 @@ template <int KP, bool CONCAT>
 __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     constexpr int M = 32, WAVES = 8;
     constexpr int CHUNKS = CONCAT ? 2 : 1;
-    constexpr int KTOT = CHUNKS * KP, KH = KTOT / 2, STEPS = KH / 16;
-    constexpr int LDB = KTOT + 8;                        // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
+    // The 512-deep concat layer (two 256-wide chunks) is contracted in two K PASSES so that a wave's W slice stays at
+    // 96 VGPRs: the accumulators of a GROUP of up to TG tiles stay in registers while pass 0 (the nodes' own rows) and
+    // pass 1 (the neighbour means) run over the group, so W is fetched and split once per pass and group, not per tile.
+    constexpr int NPASS = (CONCAT && KP == 256) ? 2 : 1;
+    constexpr int PCH = CHUNKS / NPASS;                  // K chunks staged per pass
+    constexpr int KPASS = PCH * KP;                      // K columns per pass (<= 256)
+    constexpr int KH = KPASS / 2, STEPS = KH / 16;
+    constexpr int TG = NPASS > 1 ? 4 : 1;
+    constexpr int LDB = KPASS + 8;                       // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
     constexpr int PL = M * LDB;                          // elements per plane
     constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
     static_assert(RPW % RPP == 0 && KH % 16 == 0, "tile shape");
@@ -228,117 +235,136 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const int lg = lane & (LG - 1), sg = lane / LG;
         const int c0 = lg * 4;
         const bool col_ok = c0 < a.dim;
+        const int stride = (int)gridDim.x;
 
-        f32x4 xr[PASSES], sr[CONCAT ? PASSES : 1];
-        auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
+        f32x4 xr[PCH][PASSES];
+        auto request_tile = [&](int tile, int pass) {        // global -> VGPRs, no wait
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int g = tile * M + wave * RPW + p * RPP + sg;
-                const bool valid = g < nn && col_ok;
-                xr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (valid) {
-                    xr[p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
-                    if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[p] = f32x4{q, q, q, q}; }
-                }
-                if (CONCAT) {
-                    sr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (valid) {
+            for (int pc = 0; pc < PCH; ++pc) {
+                const bool is_agg = (pass * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const int g = tile * M + wave * RPW + p * RPP + sg;
+                    const bool valid = g < nn && col_ok;
+                    xr[pc][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (valid && is_agg) {
+                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
+                        if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[pc][p] = f32x4{q, q, q, q}; }
+                    } else if (valid) {
                         const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1)
                                                        : (int64_t)min(g, a.self_rows - 1);
-                        sr[p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + c0);
+                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + c0);
                     }
                 }
             }
         };
         auto stage_tile = [&](__bf16* buf) {                  // VGPRs -> split -> three bf16 LDS planes
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int r = wave * RPW + p * RPP + sg;
-                bf16x4 hi, mid, lo;
-                split3(xr[p], hi, mid, lo);
-                __bf16* dst = buf + r * LDB + (CHUNKS - 1) * KP + c0;
-                *reinterpret_cast<bf16x4*>(dst) = hi;
-                *reinterpret_cast<bf16x4*>(dst + PL) = mid;
-                *reinterpret_cast<bf16x4*>(dst + 2 * PL) = lo;
-                if (CONCAT) {
-                    split3(sr[p], hi, mid, lo);
-                    __bf16* ds = buf + r * LDB + c0;
-                    *reinterpret_cast<bf16x4*>(ds) = hi;
-                    *reinterpret_cast<bf16x4*>(ds + PL) = mid;
-                    *reinterpret_cast<bf16x4*>(ds + 2 * PL) = lo;
+            for (int pc = 0; pc < PCH; ++pc)
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const int r = wave * RPW + p * RPP + sg;
+                    bf16x4 hi, mid, lo;
+                    split3(xr[pc][p], hi, mid, lo);
+                    __bf16* dst = buf + r * LDB + pc * KP + c0;
+                    *reinterpret_cast<bf16x4*>(dst) = hi;
+                    *reinterpret_cast<bf16x4*>(dst + PL) = mid;
+                    *reinterpret_cast<bf16x4*>(dst + 2 * PL) = lo;
                 }
-            }
         };
 
-        int tile = blockIdx.x, b = 0;
-        request_tile(tile);                                   // the first tile's rows travel while W is fetched and split
+        request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
-        // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = kgroup*KH + 16 st + 8 h in the
-        // [self | agg] K index space (chunk kk / KP, column kk % KP).  All loads of the slice are in flight at once.
+        // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = pass*KPASS + kgroup*KH + 16 st + 8 h
+        // in the [self | agg] K index space (chunk kk / KP, column kk % KP).  All loads of the slice are in flight at once.
         // (Staging W through LDS with row-contiguous loads was measured: 23.1 vs 21.1 us -- the four extra barriers cost
         // more than the uncoalesced but L2-resident 16-B loads.)
         const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
         const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
         bf16x8 bw[STEPS][3];
+        auto load_w = [&](int pass) {
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int kk = kgroup * KH + 16 * st + 8 * h;
-            const int chunk = kk / KP, kc = kk % KP;
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-            if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
-            if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc + 4);
-            bf16x4 h0, m0, l0, h1, m1, l1;
-            split3(v0, h0, m0, l0);
-            split3(v1, h1, m1, l1);
-            bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-            bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+            for (int st = 0; st < STEPS; ++st) {
+                const int kk = pass * KPASS + kgroup * KH + 16 * st + 8 * h;
+                const int chunk = kk / KP, kc = kk % KP;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+                if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
+                if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc + 4);
+                bf16x4 h0, m0, l0, h1, m1, l1;
+                split3(v0, h0, m0, l0);
+                split3(v1, h1, m1, l1);
+                bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        if (NPASS == 1) load_w(0);
 
-        for (; tile < ntiles; tile += gridDim.x, b ^= 1) {
-            __bf16* buf = lds + b * 3 * PL;
-            stage_tile(buf);
-            __syncthreads();
-            const int next = tile + gridDim.x;
-            if (next < ntiles) request_tile(next);            // in flight during the MFMA loop below
-            f32x16 acc;
+        int b = 0;
+        for (int t0 = (int)blockIdx.x; t0 < ntiles; t0 += TG * stride) {
+            f32x16 acc[TG];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            if (mfma_wave) {
-                const __bf16* abase = buf + i32 * LDB + kgroup * KH + 8 * h;
+            for (int t = 0; t < TG; ++t)
 #pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(abase + 16 * st);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(abase + PL + 16 * st);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(abase + 2 * PL + 16 * st);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw[st][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], acc, 0, 0, 0);
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                if (NPASS > 1) load_w(pass);
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const int tile = t0 + t * stride;
+                    if (tile >= ntiles) continue;             // block-uniform
+                    __bf16* buf = lds + b * 3 * PL;
+                    stage_tile(buf);
+                    __syncthreads();
+                    // the next work item's rows are in flight during the MFMA loop below
+                    if (t + 1 < TG && tile + stride < ntiles) request_tile(tile + stride, pass);
+                    else if (pass + 1 < NPASS) request_tile(t0, pass + 1);
+                    else if (t0 + TG * stride < ntiles) request_tile(t0 + TG * stride, 0);
+                    if (mfma_wave) {
+                        const __bf16* abase = buf + i32 * LDB + kgroup * KH + 8 * h;
+#pragma unroll
+                        for (int st = 0; st < STEPS; ++st) {
+                            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(abase + 16 * st);
+                            const bf16x8 am = *reinterpret_cast<const bf16x8*>(abase + PL + 16 * st);
+                            const bf16x8 al = *reinterpret_cast<const bf16x8*>(abase + 2 * PL + 16 * st);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw[st][0], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][2], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][1], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][0], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][1], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], acc[t], 0, 0, 0);
+                        }
+                    }
+                    b ^= 1;
                 }
             }
             float* myred = red + (wave & 3) * 16 * 64;        // K half 1 -> LDS -> K half 0
-            if (kgroup == 1) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) myred[e * 64 + lane] = acc[e];
-            }
-            __syncthreads();
-            if (kgroup == 0) {
+            for (int t = 0; t < TG; ++t) {
+                const int tile = t0 + t * stride;
+                if (tile >= ntiles) continue;
+                if (TG > 1 && t > 0) __syncthreads();         // the previous tile's partial sums have been read
+                if (kgroup == 1) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] += myred[e * 64 + lane];
-                const int col = n0 + i32;
-                if (mfma_wave && col < a.out_dim) {
+                    for (int e = 0; e < 16; ++e) myred[e * 64 + lane] = acc[t][e];
+                }
+                __syncthreads();
+                if (kgroup == 0) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    for (int e = 0; e < 16; ++e) acc[t][e] += myred[e * 64 + lane];
+                    const int col = n0 + i32;
+                    if (mfma_wave && col < a.out_dim) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
 #ifndef SAGE_NO_NT_STORES   // streaming stores: the next kernel reads these rows from other XCDs anyway, and dirty lines left in L2 are
                             // written back at the kernel boundary, on the critical path (gather 49.4 -> 48.3 us, contraction 22.2 -> 21.3)
-                        if (g < nn) __builtin_nontemporal_store(sage_activate(acc[reg], a.act), &a.out[(int64_t)g * a.ldo + col]);
+                            if (g < nn) __builtin_nontemporal_store(sage_activate(acc[t][reg], a.act), &a.out[(int64_t)g * a.ldo + col]);
 #else
-                        if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[reg], a.act);
+                            if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[t][reg], a.act);
 #endif
+                        }
                     }
                 }
             }
@@ -349,7 +375,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 
 template <int KP, bool CONCAT>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 3 * 32 * ((CONCAT ? 2 : 1) * KP + 8) * 2 + (size_t)4 * 16 * 64 * sizeof(float);
+    constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
+    constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)4 * 16 * 64 * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -382,7 +409,6 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
                       self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
 #ifndef SAGE_DENSE_FP32
-    // split-bf16 contraction wherever a wave's W slice fits in <= 96 VGPRs (everything but the 512-deep concat layer)
     if (!concat) {
         if (kp == 64) return launch_bf16x3<64, false>(a, st);
         if (kp == 128) return launch_bf16x3<128, false>(a, st);
@@ -390,7 +416,7 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     }
     if (kp == 64) return launch_bf16x3<64, true>(a, st);
     if (kp == 128) return launch_bf16x3<128, true>(a, st);
-    return launch<256, true>(a, st);
+    return launch_bf16x3<256, true>(a, st);
 #else
     if (!concat) {
         if (kp == 64) return launch<64, false>(a, st);

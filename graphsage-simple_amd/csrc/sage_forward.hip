@@ -64,7 +64,7 @@ extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sa
     L->h1 = take((size_t)max_s1 * m->h1 * 4);
     L->agg2 = take((size_t)B * m->h1 * 4);
     L->total_bytes = off;
-    L->layer1_split = (m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 && m->d0 >= 128 &&
+    L->layer1_split = (m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 && m->d0 >= SAGE_SPLIT_MIN_DIM &&
                        max_s1 >= 8192 && m->k1 <= 64) ? 1 : 0;
 #ifdef SAGE_FORCE_FUSED1
     L->layer1_split = 0;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
 
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k) {
     const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
-    return vec4 && dim >= 128 && n >= 8192 && k <= kWave;
+    return vec4 && dim >= SAGE_SPLIT_MIN_DIM && n >= 8192 && k <= kWave;
 }
 
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
@@ -190,13 +190,28 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
 #ifndef SAGE_G_PER_CU
 #define SAGE_G_PER_CU 8
 #endif
-#ifndef SAGE_SLICE_LANES
-#define SAGE_SLICE_LANES 16                                       // 256-B slices
+        // 256-B slices (16 lanes; 512-B rows: 29.1 us as two slices vs 32.5 us as one).  A narrow row that does not end
+        // on a slice boundary is ONE slice of 32 lanes instead (two neighbours per wave-instruction): 400-B rows
+        // (config 5) 40.5 us vs 45.5 us as a 256-B + a 144-B slice
+#ifdef SAGE_SLICE_LANES
+        constexpr bool kForce = true;
+        const int sl = SAGE_SLICE_LANES;
+#else
+        constexpr bool kForce = false;
+        const int sl = (dim <= 128 && dim % 64 != 0) ? 32 : 16;
 #endif
-        const int nslice = sage_cdiv(dim, SAGE_SLICE_LANES * 4);
+        (void)kForce;
+        const int nslice = sage_cdiv(dim, sl * 4);
         const int blocks = nslice * (kNumCU * SAGE_G_PER_CU / nslice);
-        hipLaunchKernelGGL(gather_mean_sliced_kernel<SAGE_SLICE_LANES>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
-                           n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+        if (sl == 32)
+            hipLaunchKernelGGL(gather_mean_sliced_kernel<32>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
+                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+        else if (sl == 8)
+            hipLaunchKernelGGL(gather_mean_sliced_kernel<8>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
+                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+        else
+            hipLaunchKernelGGL(gather_mean_sliced_kernel<16>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
+                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
         SAGE_CHECK_LAUNCH("gather_mean_sliced_kernel");
         return SAGE_OK;
     }

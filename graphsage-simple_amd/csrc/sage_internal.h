@@ -47,6 +47,11 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
                             sage_finish_t fin, hipStream_t st);
 
+// Narrowest layer that takes the split form (column-sliced gather + dense contraction) instead of the one-launch layer.
+#ifndef SAGE_SPLIT_MIN_DIM
+#define SAGE_SPLIT_MIN_DIM 64
+#endif
+
 #ifdef __HIPCC__
 // Finish duty of the forward's last kernel: the block that draws the last ticket zeroes the counters (keeping a
 // read-back copy for tests / byte counting) and advances the batch-queue cursor.  Split in two so that the loads
