@@ -202,18 +202,20 @@ __device__ inline void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo
     lo = __builtin_convertvector(r2, bf16x4);
 }
 
-template <int KP, bool CONCAT>
+// MP (KP = 256 only): rows wider than 256 -- every K chunk takes ceil(dim / 256) passes (Pubmed 500, Cora 1433+3 pad).
+template <int KP, bool CONCAT, bool MP>
 __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     constexpr int M = 32, WAVES = 8;
     constexpr int CHUNKS = CONCAT ? 2 : 1;
     // The 512-deep concat layer (two 256-wide chunks) is contracted in two K PASSES so that a wave's W slice stays at
     // 96 VGPRs: the accumulators of a GROUP of up to TG tiles stay in registers while pass 0 (the nodes' own rows) and
     // pass 1 (the neighbour means) run over the group, so W is fetched and split once per pass and group, not per tile.
-    constexpr int NPASS = (CONCAT && KP == 256) ? 2 : 1;
-    constexpr int PCH = CHUNKS / NPASS;                  // K chunks staged per pass
+    static_assert(!MP || KP == 256, "multi-pass rows use 256-wide passes");
+    constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1;    // K chunks staged per pass
+    constexpr bool MULTI = MP || (CONCAT && KP == 256);  // more than one pass: group accumulators
     constexpr int KPASS = PCH * KP;                      // K columns per pass (<= 256)
     constexpr int KH = KPASS / 2, STEPS = KH / 16;
-    constexpr int TG = NPASS > 1 ? 4 : 1;
+    constexpr int TG = MULTI ? 4 : 1;
     constexpr int LDB = KPASS + 8;                       // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
     constexpr int PL = M * LDB;                          // elements per plane
     constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
@@ -234,26 +236,28 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const bool mfma_wave = n0 < a.out_dim;
         const int lg = lane & (LG - 1), sg = lane / LG;
         const int c0 = lg * 4;
-        const bool col_ok = c0 < a.dim;
         const int stride = (int)gridDim.x;
+        const int ppc = MP ? (a.dim + KP - 1) / KP : 1;          // passes per K chunk
+        const int npass = (CHUNKS / PCH) * ppc;
 
         f32x4 xr[PCH][PASSES];
         auto request_tile = [&](int tile, int pass) {        // global -> VGPRs, no wait
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc) {
-                const bool is_agg = (pass * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean
+                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean
+                const int coff = (pass % ppc) * KP + c0;                         // this lane's first column of the chunk
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
                     const int g = tile * M + wave * RPW + p * RPP + sg;
-                    const bool valid = g < nn && col_ok;
+                    const bool valid = g < nn && coff < a.dim;
                     xr[pc][p] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (valid && is_agg) {
-                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
+                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff);
                         if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[pc][p] = f32x4{q, q, q, q}; }
                     } else if (valid) {
                         const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1)
                                                        : (int64_t)min(g, a.self_rows - 1);
-                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + c0);
+                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + coff);
                     }
                 }
             }
@@ -285,8 +289,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         auto load_w = [&](int pass) {
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
-                const int kk = pass * KPASS + kgroup * KH + 16 * st + 8 * h;
-                const int chunk = kk / KP, kc = kk % KP;
+                const int kk = (pass % ppc) * KPASS + kgroup * KH + 16 * st + 8 * h;       // column inside the pass's first chunk ...
+                const int chunk = (pass / ppc) * PCH + (MP ? 0 : kk / KP), kc = MP ? kk : kk % KP;   // ... or, two chunks per pass, inside its own
                 f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
                 if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
                 if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc + 4);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         };
-        if (NPASS == 1) load_w(0);
+        if (!MULTI) load_w(0);
 
         int b = 0;
         for (int t0 = (int)blockIdx.x; t0 < ntiles; t0 += TG * stride) {
@@ -307,9 +311,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
             for (int t = 0; t < TG; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                if (NPASS > 1) load_w(pass);
+            for (int pass = 0; pass < npass; ++pass) {
+                if (MULTI) load_w(pass);
 #pragma unroll
                 for (int t = 0; t < TG; ++t) {
                     const int tile = t0 + t * stride;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     __syncthreads();
                     // the next work item's rows are in flight during the MFMA loop below
                     if (t + 1 < TG && tile + stride < ntiles) request_tile(tile + stride, pass);
-                    else if (pass + 1 < NPASS) request_tile(t0, pass + 1);
+                    else if (pass + 1 < npass) request_tile(t0, pass + 1);
                     else if (t0 + TG * stride < ntiles) request_tile(t0 + TG * stride, 0);
                     if (mfma_wave) {
                         const __bf16* abase = buf + i32 * LDB + kgroup * KH + 8 * h;
@@ -373,13 +376,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-template <int KP, bool CONCAT>
+template <int KP, bool CONCAT, bool MP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)4 * 16 * 64 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess) {
             sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
@@ -387,19 +390,23 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
         configured = true;
     }
     const int grid = min(sage_cdiv(a.n, 32), kNumCU);
-    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP>), dim3(grid), dim3(512), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
     return SAGE_OK;
 }
 
 }  // namespace
 
+bool sage_layer_dense_supported(int32_t dim, int32_t out_dim) {
+    return dim >= 4 && dim % 4 == 0 && out_dim >= 1 && out_dim <= 128;
+}
+
 int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n, const int32_t* n_dev, int32_t concat,
                             const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
                             const int32_t* cnt, const int32_t* any_nonempty,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
                             sage_finish_t fin, hipStream_t st) {
-    if (!sage_layer_fused_supported(dim, out_dim, concat) || ldx % 4 != 0 || ldw % 4 != 0 || !sage_aligned(x, 16) ||
+    if (!sage_layer_dense_supported(dim, out_dim) || ldx % 4 != 0 || ldw % 4 != 0 || !sage_aligned(x, 16) ||
         !sage_aligned(weight, 16) || (concat && (ld_self % 4 != 0 || !sage_aligned(self_tab, 16)))) {
         sage_set_error("layer_dense: unsupported shape dim=%d out_dim=%d", dim, out_dim);
         return SAGE_EUNSUPPORTED;
@@ -408,6 +415,7 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     const DenseArgs a{x, ldx, dim, n, n_dev, n_off, concat ? self_tab : x, concat ? ld_self : ldx, concat ? (int)self_rows : n,
                       self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+    if (dim > 256) return concat ? launch_bf16x3<256, true, true>(a, st) : launch_bf16x3<256, false, true>(a, st);
 #ifndef SAGE_DENSE_FP32
     if (!concat) {
         if (kp == 64) return launch_bf16x3<64, false>(a, st);

@@ -64,8 +64,8 @@ extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sa
     L->h1 = take((size_t)max_s1 * m->h1 * 4);
     L->agg2 = take((size_t)B * m->h1 * 4);
     L->total_bytes = off;
-    L->layer1_split = (m->fused && sage_layer_fused_supported(m->d0, m->h1, m->concat) && m->table_ld % 4 == 0 && m->d0 >= SAGE_SPLIT_MIN_DIM &&
-                       max_s1 >= 8192 && m->k1 <= 64) ? 1 : 0;
+    L->layer1_split = (m->fused && sage_layer_dense_supported(m->d0, m->h1) && m->table_ld % 4 == 0 && m->k1 <= 64 &&
+                       ((m->d0 >= SAGE_SPLIT_MIN_DIM && max_s1 >= 8192) || m->d0 > 256)) ? 1 : 0;
 #ifdef SAGE_FORCE_FUSED1
     L->layer1_split = 0;
 #endif
@@ -136,7 +136,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                        sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
     // wide + large layer 1: column-sliced gather (cross-XCD L2 partitioning) into agg1, then a dense contraction;
     // otherwise the one-launch fused layer; otherwise the generic two-launch form
-    const bool split1 = fuse1 && L.layer1_split && sage_gather_is_sliced(m->d0, m->table_ld, m->d0, m->table, agg1, L.max_s1, m->k1);
+    const bool split1 = m->fused && L.layer1_split && sage_aligned(m->table, 16) && sage_aligned(m->w1, 16) &&
+                        sage_gather_is_sliced(m->d0, m->table_ld, m->d0, m->table, agg1, L.max_s1, m->k1);
     if (stages & SAGE_STAGE_SAMPLE) {
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
 
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k) {
     const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
-    return vec4 && dim >= SAGE_SPLIT_MIN_DIM && n >= 8192 && k <= kWave;
+    return vec4 && k <= kWave && ((dim >= SAGE_SPLIT_MIN_DIM && n >= 8192) || dim > 256);   // rows wider than 256 have no one-launch kernel
 }
 
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,

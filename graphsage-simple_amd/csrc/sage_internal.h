@@ -28,6 +28,7 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
                             hipStream_t st);
+bool sage_layer_dense_supported(int32_t dim, int32_t out_dim);
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k);
 
 int sage_launch_linear_act(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg, int64_t ld_agg,

@@ -36,6 +36,18 @@ class TwoHopEngine:
         mult = 2 if concat else 1
         if tuple(w1.shape) != (self.h1, mult * self.d0) or tuple(w2.shape) != (self.h2, mult * self.h1):
             raise native.SageError(f"weight shapes {tuple(w1.shape)}, {tuple(w2.shape)} do not fit d0={self.d0}, concat={concat}")
+        # The 16-B-per-lane kernels want row widths that are multiples of 4 floats.  Cora's 1433 raw features and the
+        # reference's default 50-wide layer 1 (model.py:543) are not: the engine then works on zero-padded copies
+        # (table once -- it is frozen, model.py:214-215 -- and the weights whenever their version counter moves).
+        # Zero weight rows / columns make the pad inert: relu(0) = 0, and sigmoid's 0.5 meets a zero column of W2.
+        self.d0p, self.h1p = -(-self.d0 // 4) * 4, -(-self.h1 // 4) * 4
+        self._padded = (self.d0p != self.d0) or (self.h1p != self.h1)
+        if self.d0p != self.d0 or self.table_ld % 4 != 0 or self.table.data_ptr() % 16 != 0:
+            padded = torch.zeros((self.table.shape[0], self.d0p), dtype=torch.float32, device=self.table.device)
+            padded[:, :self.d0] = self.table
+            self.table, self.table_ld = padded, self.d0p
+        self._wpad_key = None
+        self._w1p = self._w2p = None
         self.k1, self.k2 = int(k1), int(k2)
         self.concat, self.agg_self_loop = bool(concat), bool(agg_self_loop)
         self.act1, self.act2 = int(act1), int(act2)
@@ -53,8 +65,30 @@ class TwoHopEngine:
         self._last_batch = 0
         self._reserve(max_batch)
 
+    def _weights(self):
+        """The weight tensors the kernels read: the caller's own, or zero-padded copies kept in step with them."""
+        if not self._padded:
+            return self.w1, self.w2
+        key = (self.w1.data_ptr(), self.w1._version, self.w2.data_ptr(), self.w2._version)
+        if key != self._wpad_key:
+            m = 2 if self.concat else 1
+            if self._w1p is None:
+                self._w1p = torch.zeros((self.h1p, m * self.d0p), dtype=torch.float32, device=self.device)
+                self._w2p = torch.zeros((self.h2, m * self.h1p), dtype=torch.float32, device=self.device)
+            with torch.no_grad():
+                for c in range(m):
+                    self._w1p[:self.h1, c * self.d0p: c * self.d0p + self.d0] = self.w1[:, c * self.d0: (c + 1) * self.d0]
+                    self._w2p[:, c * self.h1p: c * self.h1p + self.h1] = self.w2[:, c * self.h1: (c + 1) * self.h1]
+            self._wpad_key = key
+        return self._w1p, self._w2p
+
+    def refresh_weights(self):
+        """Re-read the caller's weights into the padded copies (only needed between replays of a captured graph when
+        the widths are padded; `forward` does it by itself)."""
+        self._model(queued=self._queue is not None)
+
     def _model(self, queued=False):
-        w1, w2 = self.w1, self.w2
+        w1, w2 = self._weights()
         key = (w1.data_ptr(), w2.data_ptr(), self._queue.data_ptr() if self._queue is not None else 0)
         if self._model_key == key:
             return self._model_q if queued else self._model_c
@@ -64,7 +98,7 @@ class TwoHopEngine:
             raise native.SageError("weights must be contiguous")
         self._model_c = native.Model(
             self.rowptr1.data_ptr(), self.col1.data_ptr(), self.rowptr2.data_ptr(), self.col2.data_ptr(), self.num_nodes,
-            self.table.data_ptr(), self.table_ld, self.d0, w1.data_ptr(), self.h1, w2.data_ptr(), self.h2, self.k1, self.k2,
+            self.table.data_ptr(), self.table_ld, self.d0p, w1.data_ptr(), self.h1p, w2.data_ptr(), self.h2, self.k1, self.k2,
             int(self.concat), int(self.agg_self_loop), self.act1, self.act2, int(self.nan_empty), int(self.fused),
             int(self.max_batch))
         self._model_q = None
@@ -191,6 +225,6 @@ class TwoHopEngine:
             "row2": self._view(L.row2, b * self.k2, torch.int32).view(b, self.k2),
             "nbr1": self._view(L.nbr1, L.max_s1 * self.k1, torch.int32).view(L.max_s1, self.k1)[:n1],
             "cnt1": self._view(L.cnt1, L.max_s1, torch.int32)[:n1],
-            "h1": self._view(L.h1, L.max_s1 * self.h1, torch.float32).view(L.max_s1, self.h1)[:n1],
+            "h1": self._view(L.h1, L.max_s1 * self.h1p, torch.float32).view(L.max_s1, self.h1p)[:n1, :self.h1],
         }
 
