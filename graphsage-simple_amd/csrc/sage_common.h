@@ -73,11 +73,16 @@ __device__ inline int sage_hash_insert(int32_t* __restrict__ keys, uint32_t mask
     uint32_t slot = sage_hash_slot((uint32_t)id, mask);
     won = false;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
-        // look before the CAS: a hub id is inserted by hundreds of lanes of one batch (measured: the outer hop's
-        // insert took 11-28 us depending on the batch's hubs), and same-address atomics serialise at ~12 ns each
-        // while L2-served loads of one word do not.  Agent scope = bypass the (never refreshed) L1.
+        // CAS straight away.  (A look before the CAS -- one more dependent round trip for every new id -- paid while a
+        // hub id was inserted by ~1000 lanes of a batch; since the samplers dedupe inside the block first, at most one
+        // lane per block gets here with a given id, and the extra trip cost 1.5 us alone, 3 us with a second batch in
+        // flight, where every trip of this latency-bound kernel is ~3x longer.)
+#ifdef SAGE_CAS_LOAD_FIRST
         int32_t seen = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen == -1) seen = atomicCAS(&keys[slot], -1, id);
+#else
+        int32_t seen = atomicCAS(&keys[slot], -1, id);
+#endif
         if (seen == -1) { won = true; return (int)slot; }
         if (seen == id) return (int)slot;
         slot = (slot + 1) & mask;

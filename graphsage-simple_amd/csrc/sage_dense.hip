@@ -190,6 +190,9 @@ int launch(const DenseArgs& a, hipStream_t st) {
 // threads that stage them (v_cvt_pk_bf16_f32 / v_pk_add_f32, ~5 VALU per element) into three bf16 LDS planes whose rows
 // are padded by 16 B, so an A operand is ONE ds_read_b128.  The two K halves meet through LDS.  Double-buffered tiles,
 // next tile's rows in flight during the MFMA loop, as above.
+#ifndef SAGE_MP_TG
+#define SAGE_MP_TG 1
+#endif
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x8 = __attribute__((ext_vector_type(8))) float;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     constexpr bool MULTI = MP || (CONCAT && KP == 256);  // more than one pass: group accumulators
     constexpr int KPASS = PCH * KP;                      // K columns per pass (<= 256)
     constexpr int KH = KPASS / 2, STEPS = KH / 16;
-    constexpr int TG = MULTI ? 4 : 1;
+    constexpr int TG = MP ? SAGE_MP_TG : (MULTI ? 4 : 1);
     constexpr int LDB = KPASS + 8;                       // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
     constexpr int PL = M * LDB;                          // elements per plane
     constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
@@ -311,8 +314,15 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
             for (int t = 0; t < TG; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-            for (int pass = 0; pass < npass; ++pass) {
-                if (MULTI) load_w(pass);
+#pragma unroll
+            for (int pass = 0; pass < (MP ? npass : CHUNKS / PCH); ++pass) {       // compile-time trip count unless MP
+                if (MULTI) {
+                    // keep the scheduler from hoisting these loads above the previous pass's MFMAs: two live copies of
+                    // the W slice (2 x 96 VGPRs) spilled ~100 registers to scratch
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w(pass);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int t = 0; t < TG; ++t) {
                     const int tile = t0 + t * stride;

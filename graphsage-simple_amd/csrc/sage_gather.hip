@@ -110,10 +110,14 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
     float* __restrict__ out, int64_t ldo, int n_off, int nslice) {
     using V = __attribute__((ext_vector_type(4))) float;
     constexpr int NPI = kWave / SL;             // neighbours per wave-instruction
-#ifndef SAGE_G_INFLIGHT
-#define SAGE_G_INFLIGHT 4
+    // wave-instructions in flight: 8 neighbours per trip.  Deeper (4 x 4 neighbours) is no faster alone -- 32 waves per
+    // CU already cover the latency -- and costs the OTHER batch's latency-bound kernels 3.5 us per forward: every
+    // request queued here is latency added to their dependent round trips (same-box A/B, two batches in flight).
+#ifdef SAGE_G_INFLIGHT
+    constexpr int U = SAGE_G_INFLIGHT;
+#else
+    constexpr int U = 8 / NPI;
 #endif
-    constexpr int U = SAGE_G_INFLIGHT;          // wave-instructions in flight
     int nn = n;
     if (n_dev) nn = min(*n_dev + n_off, n);
     const int lane = sage_lane();
