@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-OURS = ("sample_kernel", "gather_mean", "dense_layer_kernel", "layer_fused_kernel", "linear_act_kernel")
+OURS = ("sample_kernel", "gather_mean", "dense_bf16x3_kernel", "dense_layer_kernel", "layer_tile16_kernel", "layer_fused_kernel", "linear_act_kernel")
 
 
 def short(name):
