@@ -190,6 +190,33 @@ def test_two_hop_small_rmat_all_variants(concat, self_loop, fused, d0):
     check_engine_against_oracle(graph, table, w1, w2, seeds, 10, 20, concat, self_loop, fused)
 
 
+@pytest.mark.parametrize("concat", [False, True])
+@pytest.mark.parametrize("d0,h1", [(320, 128), (500, 50), (1433, 50), (66, 30)])
+def test_two_hop_wide_and_odd_widths(d0, h1, concat):
+    """Rows wider than 256 floats (Pubmed's 500: multi-pass contraction) and widths that are not multiples of 4
+    (Cora's 1433 raw features, the reference's 50-wide layer 1, model.py:543: the engine zero-pads them) at a size where
+    layer 1 has ~15 k rows, against the fp64 oracle; the weights are changed in place afterwards to check that the
+    padded copies follow."""
+    graph = rmat_graph(14, 300_000, seed=2)
+    gen = torch.Generator().manual_seed(6)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, d0, generator=gen)
+    w1 = torch.randn(h1, m * d0, generator=gen) / np.sqrt(m * d0)
+    w2 = torch.randn(40, m * h1, generator=gen) / np.sqrt(m * h1)
+    seeds = np.random.default_rng(2).choice(np.nonzero(graph.degrees() > 0)[0], 777, replace=False)
+    check_engine_against_oracle(graph, table, w1, w2, seeds, 10, 20, concat, False, True, seed=21)
+    rowptr, col = torch.from_numpy(graph.rowptr).to(DEV), torch.from_numpy(graph.col).to(DEV)
+    w1d, w2d = w1.to(DEV), w2.to(DEV)
+    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1d, w2d, 10, 20, concat=concat, max_batch=len(seeds))
+    sd = torch.from_numpy(seeds.astype(np.int32)).to(DEV)
+    before = eng.forward(sd, seed=21).clone()
+    w1d.mul_(0.5)
+    w2d.add_(0.01)
+    after = eng.forward(sd, seed=21)
+    fresh = TwoHopEngine(rowptr, col, table.to(DEV), w1d, w2d, 10, 20, concat=concat, max_batch=len(seeds)).forward(sd, seed=21)
+    assert torch.equal(after, fresh) and not torch.equal(after, before)
+
+
 @pytest.mark.parametrize("d0", [128, 256])
 @pytest.mark.parametrize("concat", [False, True])
 def test_two_hop_isolated_seeds_take_the_nan_rule_through_the_split_layer(concat, d0):
