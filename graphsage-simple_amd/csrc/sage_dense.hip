@@ -314,8 +314,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
             for (int t = 0; t < TG; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-#pragma unroll
-            for (int pass = 0; pass < (MP ? npass : CHUNKS / PCH); ++pass) {       // compile-time trip count unless MP
+            auto do_pass = [&](int pass) {
                 if (MULTI) {
                     // keep the scheduler from hoisting these loads above the previous pass's MFMAs: two live copies of
                     // the W slice (2 x 96 VGPRs) spilled ~100 registers to scratch
@@ -351,6 +350,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     }
                     b ^= 1;
                 }
+            
+            };
+            if constexpr (MP) {
+                for (int pass = 0; pass < npass; ++pass) do_pass(pass);
+            } else {
+#pragma unroll
+                for (int pass = 0; pass < CHUNKS / PCH; ++pass) do_pass(pass);
             }
             float* myred = red + (wave & 3) * 16 * 64;        // K half 1 -> LDS -> K half 0
 #pragma unroll
