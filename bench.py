@@ -54,6 +54,8 @@ def parse():
                     help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")
     ap.add_argument("--unfused", action="store_true", help="two-launch layers (gather_mean + linear_act)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every forward from the host instead of replaying a hipGraph")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAGE_PIPELINE", "0")), choices=[0, 1],
+                    help="1: software-pipelined replay (PipelinedEngine: batch i+1 is sampled beside the contraction and layer 2 of batch i)")
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--dim", type=int, default=256)
@@ -132,7 +134,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from sage355 import native, ops
-    from sage355.engine import TwoHopEngine
+    from sage355.engine import PipelinedEngine, TwoHopEngine
     from sage355.graph import rmat_graph
     native.lib()
 
@@ -201,7 +203,21 @@ def main():
     # hipGraph replay: stream s owns steps s, s+S, s+2S, ... as a device-side queue of batch descriptors, so one
     # graph launch per step is ALL the host does inside the timed region
     use_graph = not args.no_graph
-    if use_graph:
+    # pipelined replay embeds two batches per graph launch: the step counts must split into whole pairs per stream
+    pipelined = bool(args.pipeline) and use_graph and args.warmup % (2 * nstreams) == 0 and args.steps % (2 * nstreams) == 0
+    pipes = []
+    if pipelined:
+        pair = np.arange(total_steps) // 2
+        for s in range(nstreams):
+            mine = np.nonzero(pair % nstreams == s)[0]
+            pe = PipelinedEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, agg_self_loop=args.self_loop,
+                                 fused=not args.unfused, max_batch=b)
+            pe.set_queue(seeds_dev[torch.from_numpy(mine).to(dev)].contiguous(), [sampler_seed[i] for i in mine])
+            with torch.cuda.stream(streams[s]):
+                pe.capture()
+            pipes.append(pe)
+        torch.cuda.synchronize()
+    elif use_graph:
         for s in range(nstreams):
             engines[s].set_queue(seeds_dev[s::nstreams].contiguous(), sampler_seed[s::nstreams])
             with torch.cuda.stream(streams[s]):
@@ -209,6 +225,12 @@ def main():
         torch.cuda.synchronize()
 
     def run(step_range, profiled_events=None):
+        if pipelined and profiled_events is None:
+            for j in range(step_range.start // 2, step_range.stop // 2):      # one replay = steps 2j, 2j+1
+                s = j % nstreams
+                with torch.cuda.stream(streams[s]):
+                    pipes[s].replay()
+            return
         for i in step_range:
             s = i % nstreams
             with torch.cuda.stream(streams[s]):
@@ -353,6 +375,7 @@ def main():
             "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
                        "streams_in_flight": nstreams, "fused_layers": not args.unfused, "hip_graph_replay": use_graph,
+                       "pipelined_sampling": pipelined,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
             "parity_max_err_vs_fp64_oracle": parity_err,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

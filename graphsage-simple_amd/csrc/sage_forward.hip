@@ -46,7 +46,7 @@ extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sa
     const int64_t max_s1 = B * m->k2 + B;   // frontier of B*k2 ids + B self rows (concat or self-loop)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    L->counters = take(16 * sizeof(int32_t));
+    L->counters = take(32 * sizeof(int32_t));    // 16 counters + the sampler key of a pipelined forward (sage_forward2_stages)
     L->hash_capacity = next_pow2(2 * B * (m->k2 + 1));
     L->hash_keys = take((size_t)L->hash_capacity * 4);
     L->hash_rows = take((size_t)L->hash_capacity * 4);
@@ -83,15 +83,15 @@ namespace {
     } while (0)
 
 int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
-                  uint64_t seed, float* out, int64_t ldo, sage_stream_t stream, void* const* ev) {
-    constexpr int SAGE_STAGE_SAMPLE = 1, SAGE_STAGE_GATHER = 2, SAGE_STAGE_OUTPUT = 4, stages = 7;   // kept as structure markers
+                  uint64_t seed, float* out, int64_t ldo, sage_stream_t stream, void* const* ev, int stages = SAGE_STAGE_ALL,
+                  int cursor_off = 0, bool key_in_ws = false) {
     if (int rc = check_model(m)) return rc;
     SAGE_REQUIRE(m->rowptr1 && m->col1 && m->rowptr2 && m->col2 && m->table && m->w1 && m->w2, "forward2: NULL model array");
     const bool queued = m->queue != nullptr;
     SAGE_REQUIRE(!queued || (m->queue_len >= 1 && m->queue_cursor), "forward2: batch queue without length / cursor");
-    SAGE_REQUIRE(workspace && (seeds || queued) && out, "forward2: NULL argument");
+    SAGE_REQUIRE(workspace && (seeds || queued) && (out || !(stages & SAGE_STAGE_LAYER2)), "forward2: NULL argument");
     SAGE_REQUIRE(batch >= 1, "forward2: batch = %d", batch);
-    SAGE_REQUIRE(ldo >= m->h2, "forward2: ldo = %lld < h2", (long long)ldo);
+    SAGE_REQUIRE(ldo >= m->h2 || !(stages & SAGE_STAGE_LAYER2), "forward2: ldo = %lld < h2", (long long)ldo);
     SAGE_REQUIRE(sage_aligned(workspace, 256), "forward2: workspace not 256-byte aligned");
     SAGE_REQUIRE(m->ws_batch == 0 || batch <= m->ws_batch, "forward2: batch %d > ws_batch %d", batch, m->ws_batch);
     sage_ws_layout_t L;
@@ -138,14 +138,17 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     // otherwise the one-launch fused layer; otherwise the generic two-launch form
     const bool split1 = m->fused && L.layer1_split && sage_aligned(m->table, 16) && sage_aligned(m->w1, 16) &&
                         sage_gather_is_sliced(m->d0, m->table_ld, m->d0, m->table, agg1, L.max_s1, m->k1);
-    if (stages & SAGE_STAGE_SAMPLE) {
+    uint64_t* key_slot = key_in_ws ? (uint64_t*)(counters + 16) : nullptr;    // in the 256-B slot of the counters, past the 16 ints in use
+    if (stages & SAGE_STAGE_SAMPLE_OUTER) {
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
                                     cnt2, (m->nan_empty && self_loop) ? any2 : nullptr, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
-                                    nullptr, st))
+                                    nullptr, cursor_off, key_slot, st))
         return rc;
     SAGE_EV(1);
+    }
+    if (stages & SAGE_STAGE_SAMPLE_INNER) {
     // 2. inner hop: S1 -> nbr1 (raw table rows; duplicates are served by L2 / Infinity Cache).  Its spare
     //    threads turn the outer hop's hash slots into frontier rows and wipe the used keys.
     //    (Drawing these samples inside the layer-1 gather instead was measured: the gather went from 48 to
@@ -154,12 +157,12 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     SAGE_EV(2);
     if (int rc = sage_launch_sample(m->rowptr1, m->col1, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
                                     SAGE_TAG_INNER_SELF, nbr1, cnt1, m->nan_empty ? any1 : nullptr, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
-                                    &resolve, st))
+                                    &resolve, cursor_off, key_slot, st))
         return rc;
     SAGE_EV(3);
     }
     // 3. layer 1 on S1: the HBM-bound gather ...
-    if (stages & SAGE_STAGE_GATHER) {
+    if (stages & SAGE_STAGE_GATHER1) {
     SAGE_EV(4);
     if (split1) {
         if (int rc = sage_launch_gather_mean(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
@@ -169,7 +172,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     SAGE_EV(5);
     }
     // ... and its contraction (one launch with the gather unless the layer is split); then layer 2
-    if (stages & SAGE_STAGE_OUTPUT) {
+    if (stages & SAGE_STAGE_CONTRACT1) {
     SAGE_EV(6);
     if (split1) {
         if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
@@ -189,6 +192,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
             return rc;
     }
     SAGE_EV(7);
+    }
+    if (stages & SAGE_STAGE_LAYER2) {
     // 4. layer 2 on the seeds; its last block zeroes the counters and advances the batch queue
     SAGE_EV(8);
     const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat) && sage_aligned(m->w2, 16);
@@ -214,6 +219,14 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
 extern "C" int sage_forward2(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                              uint64_t seed, float* out, int64_t ldo, sage_stream_t stream) {
     return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, stream, nullptr);
+}
+
+extern "C" int sage_forward2_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t batch, float* out,
+                                    int64_t ldo, int32_t stages, int32_t cursor_offset, sage_stream_t stream) {
+    SAGE_REQUIRE(m && m->queue, "forward2_stages: needs a batch queue (model.queue)");
+    SAGE_REQUIRE(stages > 0 && stages <= SAGE_STAGE_ALL, "forward2_stages: stages = %d", stages);
+    SAGE_REQUIRE(cursor_offset >= 0, "forward2_stages: cursor_offset = %d", cursor_offset);
+    return forward2_impl(m, workspace, workspace_bytes, nullptr, batch, 0, out, ldo, stream, nullptr, stages, cursor_offset, true);
 }
 
 extern "C" int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds,

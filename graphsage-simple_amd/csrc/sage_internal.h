@@ -22,7 +22,7 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, const int32_t*
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
                        int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* queue_model,
                        int nodes_from_batch, int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off,
-                       const sage_resolve_t* resolve, hipStream_t st);
+                       const sage_resolve_t* resolve, int32_t cursor_off, uint64_t* key_slot, hipStream_t st);
 
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,

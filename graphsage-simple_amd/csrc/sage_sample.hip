@@ -28,6 +28,9 @@ struct BatchSrc {
     int len;
     int nodes_from_batch;     // outer hop: nodes = descriptor seeds; inner hop: only the key
     int32_t* nodes_copy;      // nullable: nodes[r] is also written here (concat: seeds head S1)
+    int cursor_off;           // descriptor = queue[(*cursor + cursor_off) % len]  (pipelined forwards sample one batch ahead)
+    uint64_t* key_slot;       // nullable: the outer hop leaves the sampler key here, the inner hop takes it from here
+                              // instead of the queue (it then never reads the cursor, which another batch's last kernel advances)
 };
 
 struct FrontierDev {
@@ -99,10 +102,19 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
         }
     }
     if (bs.queue) {
-        const sage_batch_t b = bs.queue[*bs.cursor % bs.len];
-        key0 = (uint32_t)b.seed;
-        key1 = (uint32_t)(b.seed >> 32);
-        if (bs.nodes_from_batch) nodes = b.seeds;
+        if (bs.key_slot && !bs.nodes_from_batch) {
+            const uint64_t kq = *bs.key_slot;
+            key0 = (uint32_t)kq;
+            key1 = (uint32_t)(kq >> 32);
+        } else {
+            const sage_batch_t b = bs.queue[(uint32_t)(*bs.cursor + bs.cursor_off) % (uint32_t)bs.len];
+            key0 = (uint32_t)b.seed;
+            key1 = (uint32_t)(b.seed >> 32);
+            if (bs.nodes_from_batch) {
+                nodes = b.seeds;
+                if (bs.key_slot && blockIdx.x == 0 && tid == 0) *bs.key_slot = b.seed;
+            }
+        }
     }
     const bool active = r < nn;
     int32_t v = -1, id = -1;
@@ -248,10 +260,12 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, const int32_t*
                        int32_t k, uint64_t seed, uint32_t tag, int32_t tag_self_rows, uint32_t tag_self,
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
                        int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* qm, int nodes_from_batch,
-                       int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off, const sage_resolve_t* resolve, hipStream_t st) {
+                       int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off, const sage_resolve_t* resolve,
+                       int32_t cursor_off, uint64_t* key_slot, hipStream_t st) {
     if (n == 0) return SAGE_OK;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const BatchSrc bs{qm ? qm->queue : nullptr, qm ? qm->queue_cursor : nullptr, qm ? qm->queue_len : 0, nodes_from_batch, nodes_copy};
+    const BatchSrc bs{qm ? qm->queue : nullptr, qm ? qm->queue_cursor : nullptr, qm ? qm->queue_len : 0, nodes_from_batch, nodes_copy,
+                      cursor_off, key_slot};
     ResolveJob rj{};
     if (resolve) rj = ResolveJob{resolve->slots, resolve->rows_out, resolve->n_slots, resolve->self_slots, resolve->self_rows_out,
                                  resolve->n_self, resolve->hash_rows, resolve->hash_keys};
@@ -294,7 +308,7 @@ extern "C" int sage_sample_neighbors(const int64_t* rowptr, const int32_t* col, 
         SAGE_REQUIRE(!insert_self || self_slot, "sample_neighbors: insert_self needs self_slot");
     }
     return sage_launch_sample(rowptr, col, nodes, n, n_dev, k, seed, tag, 0, tag, nbr, cnt, any_nonempty, frontier, insert_self,
-                              nbr_slot, self_slot, nullptr, 0, nullptr, 0, 0, nullptr, (hipStream_t)stream);
+                              nbr_slot, self_slot, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int32_t k, const int32_t* self_nodes, int32_t n,
@@ -312,7 +326,7 @@ extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int3
     const int32_t* no32 = nullptr;
     launch_by_fanout<false, true>(k, n, (hipStream_t)stream, no64, no32, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt,
                                   (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, fd, self_nodes ? 1 : 0, nbr_slot,
-                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr}, 0, ResolveJob{});
+                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr}, 0, ResolveJob{});
     SAGE_CHECK_LAUNCH("frontier_insert_kernel");
     return SAGE_OK;
 }
