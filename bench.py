@@ -54,8 +54,9 @@ def parse():
                     help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")
     ap.add_argument("--unfused", action="store_true", help="two-launch layers (gather_mean + linear_act)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every forward from the host instead of replaying a hipGraph")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAGE_PIPELINE", "0")), choices=[0, 1],
-                    help="1: software-pipelined replay (PipelinedEngine: batch i+1 is sampled beside the contraction and layer 2 of batch i)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAGE_PIPELINE", "0")), choices=[0, 1, 2],
+                    help="software-pipelined replay (PipelinedEngine).  1: batch i+1 is sampled beside the contraction and layer 2 of "
+                         "batch i (graph branches); 2: its outer sample shares ONE launch with the gather of batch i")
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--dim", type=int, default=256)
@@ -211,7 +212,7 @@ def main():
         for s in range(nstreams):
             mine = np.nonzero(pair % nstreams == s)[0]
             pe = PipelinedEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, agg_self_loop=args.self_loop,
-                                 fused=not args.unfused, max_batch=b)
+                                 fused=not args.unfused, max_batch=b, mode="fused" if args.pipeline == 2 else "branches")
             pe.set_queue(seeds_dev[torch.from_numpy(mine).to(dev)].contiguous(), [sampler_seed[i] for i in mine])
             with torch.cuda.stream(streams[s]):
                 pe.capture()

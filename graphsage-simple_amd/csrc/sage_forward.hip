@@ -229,6 +229,44 @@ extern "C" int sage_forward2_stages(const sage_model_t* m, void* workspace, size
     return forward2_impl(m, workspace, workspace_bytes, nullptr, batch, 0, out, ldo, stream, nullptr, stages, cursor_offset, true);
 }
 
+// gather(batch at the cursor, workspace `cur`) + outer sample(next batch, workspace `next`) as ONE launch (sage_pipeline.hip)
+extern "C" int sage_forward2_gather_sample(const sage_model_t* m, void* ws_cur, void* ws_next, size_t workspace_bytes, int32_t batch,
+                                           int32_t cursor_offset, sage_stream_t stream) {
+    if (int rc = check_model(m)) return rc;
+    SAGE_REQUIRE(m->queue && m->queue_len >= 1 && m->queue_cursor, "forward2_gather_sample: needs a batch queue (model.queue)");
+    SAGE_REQUIRE(ws_cur && ws_next && ws_cur != ws_next && sage_aligned(ws_cur, 256) && sage_aligned(ws_next, 256),
+                 "forward2_gather_sample: two distinct 256-byte aligned workspaces");
+    SAGE_REQUIRE(batch >= 1 && (m->ws_batch == 0 || batch <= m->ws_batch) && cursor_offset >= 0, "forward2_gather_sample: batch = %d", batch);
+    sage_ws_layout_t L;
+    if (int rc = sage_forward2_layout(m, m->ws_batch ? m->ws_batch : batch, &L)) return rc;
+    if (L.total_bytes > workspace_bytes) {
+        sage_set_error("forward2_gather_sample: workspace %zu bytes < %zu needed", workspace_bytes, L.total_bytes);
+        return SAGE_ENOSPACE;
+    }
+    const bool split1 = m->fused && L.layer1_split && sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
+    if (split1) {
+        char* wc = (char*)ws_cur;
+        char* wn = (char*)ws_next;
+        int32_t* cc = (int32_t*)(wc + L.counters);
+        int32_t* cn = (int32_t*)(wn + L.counters);
+        const int self_loop = m->agg_self_loop ? 1 : 0;
+        const int first_row = m->concat ? batch : 0;
+        int32_t* s1_nodes_c = (int32_t*)(wc + L.s1_nodes);
+        int32_t* s1_nodes_n = (int32_t*)(wn + L.s1_nodes);
+        const sage_frontier_t fr{(int32_t*)(wn + L.hash_keys), (int32_t*)(wn + L.hash_rows), L.hash_capacity, s1_nodes_n, cn + 0, L.max_s1};
+        const int rc = sage_launch_gather_plus_sample(
+            m->table, m->num_nodes, m->table_ld, m->d0, (const int32_t*)(wc + L.nbr1), (const int32_t*)(wc + L.cnt1), m->k1, L.max_s1, cc + 0,
+            self_loop ? s1_nodes_c : nullptr, m->nan_empty ? cc + 2 : nullptr, (float*)(wc + L.agg1), m->d0, first_row,
+            m->rowptr2, m->col2, batch, m->k2, SAGE_TAG_OUTER, (int32_t*)(wn + L.nbr2), (int32_t*)(wn + L.cnt2),
+            (m->nan_empty && self_loop) ? cn + 1 : nullptr, &fr, self_loop, (int32_t*)(wn + L.slot2), (int32_t*)(wn + L.self_slot2), m,
+            m->concat ? s1_nodes_n : nullptr, first_row, cursor_offset, (uint64_t*)(cn + 16), (hipStream_t)stream);
+        if (rc != SAGE_EUNSUPPORTED) return rc;
+    }
+    // no fused launch for this shape: the two pieces one after the other
+    if (int rc = forward2_impl(m, ws_cur, workspace_bytes, nullptr, batch, 0, nullptr, 0, stream, nullptr, SAGE_STAGE_GATHER1, 0, true)) return rc;
+    return forward2_impl(m, ws_next, workspace_bytes, nullptr, batch, 0, nullptr, 0, stream, nullptr, SAGE_STAGE_SAMPLE_OUTER, cursor_offset, true);
+}
+
 extern "C" int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds,
                                       int32_t batch, uint64_t seed, float* out, int64_t ldo, sage_stream_t stream,
                                       void* const* stage_events) {

@@ -28,6 +28,13 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
                             hipStream_t st);
+int sage_launch_gather_plus_sample(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr1,
+                                   const int32_t* cnt1, int32_t k1, int32_t n1, const int32_t* n1_dev, const int32_t* self_row,
+                                   const int32_t* any1, float* agg, int64_t ldo, int32_t n_off,
+                                   const int64_t* rowptr2, const int32_t* col2, int32_t batch, int32_t k2, uint32_t tag,
+                                   int32_t* nbr2, int32_t* cnt2, int32_t* any2, const sage_frontier_t* frontier, int32_t insert_self,
+                                   int32_t* slot2, int32_t* self_slot2, const sage_model_t* qm, int32_t* nodes_copy,
+                                   int32_t frontier_row_off, int32_t cursor_off, uint64_t* key_slot, hipStream_t st);
 bool sage_layer_dense_supported(int32_t dim, int32_t out_dim);
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k);
 

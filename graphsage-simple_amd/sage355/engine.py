@@ -243,7 +243,13 @@ class PipelinedEngine:
     TwoHopEngine.forward on the same seeds and keys; the reference itself has no counterpart (model.py:240-249
     processes one batch at a time)."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, mode="branches", **kwargs):
+        """mode "branches": the graph above.  mode "fused": one stream,
+               [gather(i) + outer sample(i+1) in ONE launch] -> contract(i) -> layer 2(i) -> inner sample(i+1)
+        (sage_forward2_gather_sample): one graph node less per forward and the outer sampler off the critical path."""
+        if mode not in ("branches", "fused"):
+            raise native.SageError("PipelinedEngine: mode must be 'branches' or 'fused'")
+        self.mode = mode
         self.e = [TwoHopEngine(*args, **kwargs), TwoHopEngine(*args, **kwargs)]
         self.device = self.e[0].device
         self._graph = None
@@ -273,6 +279,16 @@ class PipelinedEngine:
 
     def _double_step(self, out, side):
         cur = torch.cuda.current_stream()
+        if self.mode == "fused":
+            for p in (0, 1):
+                a, b = self.e[p], self.e[1 - p]
+                rc = native.lib().sage_forward2_gather_sample(a._model(queued=True), a.workspace.data_ptr(), b.workspace.data_ptr(),
+                                                              a.workspace.numel(), a._queue_batch, 1, cur.cuda_stream)
+                if rc != 0:
+                    native.check(rc, "forward2_gather_sample")
+                self._stages(p, native.STAGE_CONTRACT1 | native.STAGE_LAYER2, out=out[p])
+                self._stages(1 - p, native.STAGE_SAMPLE_INNER)
+            return
         for p in (0, 1):
             q = 1 - p
             self._stages(p, native.STAGE_GATHER1)

@@ -289,8 +289,9 @@ def test_graph_replay_of_queued_batches_equals_direct_calls():
             assert torch.equal(out, want[i]), f"concat={concat} after rewind, batch {i}"
 
 
+@pytest.mark.parametrize("mode", ["branches", "fused"])
 @pytest.mark.parametrize("concat,self_loop,d0", [(False, False, 256), (True, False, 256), (False, True, 100), (True, True, 64)])
-def test_pipelined_replay_equals_direct_calls(concat, self_loop, d0):
+def test_pipelined_replay_equals_direct_calls(concat, self_loop, d0, mode):
     """sage_forward2_stages / PipelinedEngine: sampling batch i+1 beside the contraction and layer 2 of batch i (two
     workspaces, parallel graph branches) must give, batch for batch, the bits of the plain forward -- over several
     replays (each embeds two batches), around the ring, and after a rewind."""
@@ -307,7 +308,7 @@ def test_pipelined_replay_equals_direct_calls(concat, self_loop, d0):
     keys = [11, 2**63 + 5, 13, 2**64 - 1, 17, 19]
     direct = TwoHopEngine(rowptr, col, table, w1, w2, 15, 25, concat=concat, agg_self_loop=self_loop, max_batch=600)
     want = [direct.forward(seeds[i], seed=keys[i]).clone() for i in range(nb)]
-    pipe = PipelinedEngine(rowptr, col, table, w1, w2, 15, 25, concat=concat, agg_self_loop=self_loop, max_batch=600)
+    pipe = PipelinedEngine(rowptr, col, table, w1, w2, 15, 25, concat=concat, agg_self_loop=self_loop, max_batch=600, mode=mode)
     pipe.set_queue(seeds, keys)
     out = pipe.capture()
     for rnd in range(2):                            # second round: the ring wraps around
