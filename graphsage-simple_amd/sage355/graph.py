@@ -143,7 +143,10 @@ def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, 
     if cache_dir is not None:
         fr, fc = os.path.join(cache_dir, tag + "_rowptr.npy"), os.path.join(cache_dir, tag + "_col.npy")
         if os.path.exists(fr) and os.path.exists(fc):
-            return CSRGraph(np.load(fr), np.load(fc), 1 << scale)
+            try:
+                return CSRGraph(np.load(fr), np.load(fc), 1 << scale)
+            except (OSError, ValueError, EOFError):
+                pass                               # unreadable cache: regenerate
     rng = np.random.default_rng(seed)
     n = 1 << scale
     keys = []
@@ -171,9 +174,14 @@ def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, 
     np.cumsum(np.bincount(src, minlength=n), out=rowptr[1:])
     g = CSRGraph(rowptr, dst.astype(np.int32), n)
     if cache_dir is not None:
+        # several ranks of one node generate the same graph at the same time (bench.py --gpus N): each writes its own
+        # temporary file and renames it into place, so a reader never sees a half-written cache (col first: the
+        # reader's test is "both exist", and rowptr appearing last makes the pair complete)
         os.makedirs(cache_dir, exist_ok=True)
-        np.save(fr, g.rowptr)
-        np.save(fc, g.col)
+        for path, arr in ((fc, g.col), (fr, g.rowptr)):
+            tmp = f"{path}.{os.getpid()}.tmp.npy"
+            np.save(tmp, arr)
+            os.replace(tmp, path)
     return g
 
 
