@@ -126,7 +126,8 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     const sage_finish_t fin{counters, queued ? m->queue_cursor : nullptr};
 
     // The workspace is self-cleaning (sage_forward2_init once, then every forward leaves the hash
-    // keys wiped and the counters zero), so a forward is exactly 4 launches (6 with two-launch layers).
+    // keys wiped and the counters zero), so a forward is exactly 4 launches (5 when layer 1 is split into
+    // gather + contraction, 6 with the generic two-launch layers).
     const int64_t ldw1 = (int64_t)m->d0 * (m->concat ? 2 : 1);
     const int64_t ldw2 = (int64_t)m->h1 * (m->concat ? 2 : 1);
     const int32_t* nan1 = m->nan_empty ? any1 : nullptr;

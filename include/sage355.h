@@ -263,7 +263,7 @@ typedef struct {
 int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sage_ws_layout_t* layout_host);
 
 /* The workspace is self-cleaning: each forward wipes the hash keys it used and its last
- * kernel zeroes the device counters, so a forward is 4 launches with no memset / reset.
+ * kernel zeroes the device counters, so a forward is 4-5 launches with no memset / reset.
  * sage_forward2_init puts a freshly allocated workspace into that state (call it once,
  * with the LARGEST batch the workspace will see, and use one batch size per workspace
  * thereafter: the layout, hence the key array, depends on it). */
