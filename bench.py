@@ -54,6 +54,9 @@ def parse():
                     help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")
     ap.add_argument("--unfused", action="store_true", help="two-launch layers (gather_mean + linear_act)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every forward from the host instead of replaying a hipGraph")
+    ap.add_argument("--batches-per-replay", type=int, default=0,
+                    help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "
+                         "whose 20 us of GPU work per batch is less than one graph launch costs the host)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAGE_PIPELINE", "0")), choices=[0, 1, 2],
                     help="software-pipelined replay (PipelinedEngine).  1: batch i+1 is sampled beside the contraction and layer 2 of "
                          "batch i (graph branches); 2: its outer sample shares ONE launch with the gather of batch i")
@@ -207,6 +210,7 @@ def main():
     # pipelined replay embeds two batches per graph launch: the step counts must split into whole pairs per stream
     pipelined = bool(args.pipeline) and use_graph and args.warmup % (2 * nstreams) == 0 and args.steps % (2 * nstreams) == 0
     pipes = []
+    bpr = args.batches_per_replay if args.batches_per_replay > 0 else (10 if args.config == 2 else 1)
     if pipelined:
         pair = np.arange(total_steps) // 2
         for s in range(nstreams):
@@ -219,10 +223,17 @@ def main():
             pipes.append(pe)
         torch.cuda.synchronize()
     elif use_graph:
+        if bpr > 1 and (args.warmup % (bpr * nstreams) or args.steps % (bpr * nstreams)):
+            bpr = 1                                   # the step counts must split into whole replays per stream
+        group = np.arange(total_steps) // bpr
         for s in range(nstreams):
-            engines[s].set_queue(seeds_dev[s::nstreams].contiguous(), sampler_seed[s::nstreams])
+            mine = torch.from_numpy(np.nonzero(group % nstreams == s)[0]).to(dev)
+            engines[s].set_queue(seeds_dev[mine].contiguous(), [sampler_seed[int(i)] for i in mine.cpu()])
             with torch.cuda.stream(streams[s]):
-                engines[s].capture(out=outs[s])
+                if bpr == 1:
+                    engines[s].capture(out=outs[s])
+                else:
+                    engines[s].capture(batches=bpr)
         torch.cuda.synchronize()
 
     def run(step_range, profiled_events=None):
@@ -231,6 +242,12 @@ def main():
                 s = j % nstreams
                 with torch.cuda.stream(streams[s]):
                     pipes[s].replay()
+            return
+        if use_graph and bpr > 1 and profiled_events is None:
+            for j in range(step_range.start // bpr, step_range.stop // bpr):  # one replay = steps j*bpr .. j*bpr + bpr - 1
+                s = j % nstreams
+                with torch.cuda.stream(streams[s]):
+                    engines[s].replay()
             return
         for i in step_range:
             s = i % nstreams
@@ -376,7 +393,7 @@ def main():
             "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
                        "streams_in_flight": nstreams, "fused_layers": not args.unfused, "hip_graph_replay": use_graph,
-                       "pipelined_sampling": pipelined,
+                       "pipelined_sampling": pipelined, "batches_per_replay": 2 if pipelined else (bpr if use_graph else 1),
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
             "parity_max_err_vs_fp64_oracle": parity_err,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -142,23 +142,31 @@ class TwoHopEngine:
         self._last_batch = self._queue_batch
         return out
 
-    def capture(self, out=None):
-        """Capture one queued forward into a hipGraph (torch.cuda.CUDAGraph); replay() then runs
-        batch after batch with a single graph launch each."""
+    def capture(self, out=None, batches=1):
+        """Capture queued forwards into a hipGraph (torch.cuda.CUDAGraph); replay() then runs batch after batch with a
+        single graph launch each.  batches > 1: one replay embeds that many consecutive batches of the ring into
+        out[0..batches-1] -- for small batches (Pubmed's 256 seeds: 20 us of GPU work) the host's graph launch is
+        otherwise the bottleneck."""
         if self._queue is None:
             raise native.SageError("capture: call set_queue first")
+        batches = int(batches)
+        shape = (self._queue_batch, self.h2) if batches == 1 else (batches, self._queue_batch, self.h2)
         if out is None:
-            out = torch.empty((self._queue_batch, self.h2), dtype=torch.float32, device=self.device)
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != shape:
+            raise native.SageError(f"capture: `out` must have shape {shape}")
         self._graph_out = out
+        outs = [out] if batches == 1 else [out[j] for j in range(batches)]
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up outside capture (function attributes, lazy init)
-            self.forward_queued(out)
+            self.forward_queued(outs[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.forward_queued(out)
+            for o in outs:
+                self.forward_queued(o)
         self._graph = g
         self._cursor.zero_()
         torch.cuda.synchronize()

@@ -287,6 +287,15 @@ def test_graph_replay_of_queued_batches_equals_direct_calls():
             eng.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, want[i]), f"concat={concat} after rewind, batch {i}"
+        # several batches per replay (one graph launch embeds three consecutive ring entries)
+        multi = TwoHopEngine(rowptr, col, table, w1c, w2c, 15, 25, concat=concat, max_batch=600)
+        multi.set_queue(seeds, keys)
+        out3 = multi.capture(batches=3)
+        for first in (0, 3, 1):                    # 0-2, 3-4-0 (wraps), 1-3
+            multi.replay()
+            torch.cuda.synchronize()
+            for j in range(3):
+                assert torch.equal(out3[j], want[(first + j) % 5]), f"concat={concat} multi-batch replay, batch {(first + j) % 5}"
 
 
 @pytest.mark.parametrize("mode", ["branches", "fused"])
