@@ -395,9 +395,13 @@ __global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
 
 template <int KP, bool CONCAT>
 int launch_tile16(const FusedArgs& a, hipStream_t st) {
-    // neighbour lists up to NPI x INFLIGHT entries are fetched in one trip: 26 (KP = 128) / 52 (KP = 64);
-    // the concat form keeps two W chunks in VGPRs and so has half the room for loads in flight
-    constexpr int INFLIGHT = CONCAT ? 7 : 13;
+    // neighbour lists up to NPI x INFLIGHT entries are fetched in one trip: 14 (KP = 128) / 28 (KP = 64).  13 in flight (the
+    // whole 25-entry list of config 3 in ONE trip, 110 VGPRs) is no faster alone and 1.4 us per forward slower with a second
+    // batch in flight than 7 (two trips, 86 VGPRs): the smaller block shares a CU more easily (same-box A/B, 3 x 3 runs)
+#ifndef SAGE_T16_INFLIGHT
+#define SAGE_T16_INFLIGHT 7
+#endif
+    constexpr int INFLIGHT = CONCAT ? 7 : SAGE_T16_INFLIGHT;
     const int tiles = sage_cdiv(a.n, 16);
     const int grid = min(tiles, 2 * kNumCU);
     hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT>), dim3(grid), dim3(1024), 0, st, a);

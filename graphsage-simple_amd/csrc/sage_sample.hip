@@ -74,7 +74,10 @@ void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
 #define SAGE_SO_THREADS 1024
 #endif
     if constexpr (FRONTIER) launch_by_fanout_t<SAGE_SO_THREADS, SAMPLE, FRONTIER>(k, n, st, args...);
-    else launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, n, st, args...);
+#ifndef SAGE_SI_THREADS
+#define SAGE_SI_THREADS 256
+#endif
+    else launch_by_fanout_t<SAGE_SI_THREADS, SAMPLE, FRONTIER>(k, n, st, args...);
 }
 
 }  // namespace
