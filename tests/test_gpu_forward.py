@@ -217,6 +217,54 @@ def test_two_hop_wide_and_odd_widths(d0, h1, concat):
     assert torch.equal(after, fresh) and not torch.equal(after, before)
 
 
+@pytest.mark.parametrize("concat", [False, True])
+@pytest.mark.parametrize("b,k1,k2", [(1, 15, 25), (17, 3, 40), (300, 64, 5), (64, 8, 64)])
+def test_two_hop_odd_batches_and_fanouts(b, k1, k2, concat):
+    """One seed, a batch that is no multiple of any tile, fanouts on both sides of every group width (3, 5, 8 | 40, 64:
+    lane groups of 8, 16 and 64) -- sets bit-exact against the C sampler, values against the fp64 oracle."""
+    graph = rmat_graph(13, 150_000, seed=4)
+    gen = torch.Generator().manual_seed(8)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, 128, generator=gen)
+    w1 = torch.randn(64, m * 128, generator=gen) / np.sqrt(m * 128)
+    w2 = torch.randn(32, m * 64, generator=gen) / np.sqrt(m * 64)
+    seeds = np.random.default_rng(b).choice(np.nonzero(graph.degrees() > 0)[0], b, replace=False)
+    check_engine_against_oracle(graph, table, w1, w2, seeds, k1, k2, concat, False, True, seed=5)
+
+
+@pytest.mark.parametrize("concat", [False, True])
+def test_two_hop_all_isolated_batch_gives_zeros_not_nan(concat):
+    """aggregators.py:60-61 when NO node of the call has a neighbour: the mask has zero columns, 0/0 never happens and
+    the reference returns zeros (relu(W.0) = 0) -- also through the engine, where the frontier stays empty."""
+    graph = rmat_graph(13, 150_000, seed=4)
+    lonely = np.nonzero(graph.degrees() == 0)[0][:50]
+    assert len(lonely) == 50
+    gen = torch.Generator().manual_seed(9)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, 128, generator=gen)
+    w1 = torch.randn(64, m * 128, generator=gen) / 16
+    w2 = torch.randn(32, m * 64, generator=gen) / 8
+    rowptr, col = torch.from_numpy(graph.rowptr).to(DEV), torch.from_numpy(graph.col).to(DEV)
+    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), 10, 25, concat=concat, max_batch=50)
+    out = eng.forward(torch.from_numpy(lonely.astype(np.int32)).to(DEV), seed=3).cpu()
+    assert not torch.isnan(out).any()
+    it = eng.intermediates()
+    assert not it["cnt2"].cpu().numpy().any() and it["n_s1"] == (50 if concat else 0)
+    # every aggregate of the call is the all-empty batch's zeros: gcn -> relu(W.0) = 0; concat -> only the nodes' own rows count
+    if concat:
+        x = table[torch.from_numpy(lonely)].double()
+        h1_self = torch.relu(x @ w1[:, :128].double().t())
+        ref = torch.relu(h1_self @ w2[:, :64].double().t())
+    else:
+        ref = torch.zeros(50, 32, dtype=torch.float64)
+    assert_close_rowmax(out, ref, what="all-isolated batch")
+    # and the next, ordinary batch on the same engine is unaffected (the workspace cleaned itself)
+    seeds = np.random.default_rng(1).choice(np.nonzero(graph.degrees() > 0)[0], 50, replace=False)
+    a = eng.forward(torch.from_numpy(seeds.astype(np.int32)).to(DEV), seed=4).clone()
+    fresh = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), 10, 25, concat=concat, max_batch=50)
+    assert torch.equal(a, fresh.forward(torch.from_numpy(seeds.astype(np.int32)).to(DEV), seed=4))
+
+
 @pytest.mark.parametrize("d0", [128, 256])
 @pytest.mark.parametrize("concat", [False, True])
 def test_two_hop_isolated_seeds_take_the_nan_rule_through_the_split_layer(concat, d0):
