@@ -14,7 +14,7 @@ from .ops import ACT_RELU, _chk, _need_gpu, _row_major, as_ids
 
 class TwoHopEngine:
     def __init__(self, rowptr, col, table, w1, w2, k1, k2, concat=False, agg_self_loop=False, act1=ACT_RELU,
-                 act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None):
+                 act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None, relabel=None):
         """rowptr/col: CSR of enc1.adj_lists (inner hop); rowptr_outer/col_outer: CSR of
         enc2.adj_lists when it differs (injected pre-sampled sets), default the same.
         w1 [h1, d0 | 2*d0], w2 [h2, h1 | 2*h1]: the Encoders' `weight` Parameters
@@ -27,6 +27,15 @@ class TwoHopEngine:
         if self.rowptr2.shape[0] != self.rowptr1.shape[0]:
             raise native.SageError("inner and outer CSR must cover the same node ids")
         self.table, self.table_ld = _row_major(table, "table")
+        # relabel="degree": work on a copy of graph and table renumbered by descending degree, so that the rows gathered
+        # most often are neighbours in memory (config 3: gather 45 -> 43 us, forward 81 -> 77 us).  Seeds are translated on
+        # the way in; ids in intermediates() are the INTERNAL ones (self.node_order[i] = caller's id of internal node i).
+        # The device sampler is keyed by node id, so the sampled sets differ from the unrelabelled engine's (same law).
+        self.node_order = self._new_of_old = None
+        if relabel not in (None, "degree"):
+            raise native.SageError("relabel must be None or 'degree'")
+        if relabel == "degree":
+            self._relabel_by_degree()
         self.num_nodes = self.rowptr1.shape[0] - 1
         if self.table.shape[0] < self.num_nodes:
             raise native.SageError(f"table has {self.table.shape[0]} rows for {self.num_nodes} nodes")
@@ -64,6 +73,35 @@ class TwoHopEngine:
         self._graph = None
         self._last_batch = 0
         self._reserve(max_batch)
+
+    def _relabel_by_degree(self):
+        n = self.rowptr1.shape[0] - 1
+        deg = self.rowptr1[1:] - self.rowptr1[:-1]
+        order = torch.sort(deg, descending=True, stable=True).indices           # internal -> caller's id
+        new_of_old = torch.empty_like(order)
+        new_of_old[order] = torch.arange(n, device=order.device)
+
+        def renumber(rowptr, col):
+            d = rowptr[1:] - rowptr[:-1]
+            src = new_of_old[torch.repeat_interleave(torch.arange(n, device=col.device), d)]
+            key = torch.sort(src * n + new_of_old[col.long()]).values
+            rp = torch.zeros(n + 1, dtype=torch.int64, device=col.device)
+            rp[1:] = torch.cumsum(d[order], 0)
+            return rp, (key % n).to(torch.int32)
+
+        same = self.rowptr2 is self.rowptr1 and self.col2 is self.col1
+        rp1, c1 = renumber(self.rowptr1, self.col1)
+        if same:
+            rp2, c2 = rp1, c1
+        else:
+            rp2, c2 = renumber(self.rowptr2, self.col2)
+        self.rowptr1, self.col1, self.rowptr2, self.col2 = rp1, c1, rp2, c2
+        self.table = self.table[order].contiguous()
+        self.table_ld = self.table.shape[1]
+        self.node_order, self._new_of_old = order, new_of_old.to(torch.int32)
+
+    def _seeds_in(self, seeds):
+        return seeds if self._new_of_old is None else self._new_of_old[seeds.long()]
 
     def _weights(self):
         """The weight tensors the kernels read: the caller's own, or zero-padded copies kept in step with them."""
@@ -120,6 +158,7 @@ class TwoHopEngine:
         s, b = seeds.shape
         if len(rng_seeds) != s:
             raise native.SageError("set_queue: one sampler key per batch")
+        seeds = self._seeds_in(seeds).contiguous()
         self._reserve(b)
         desc = torch.empty((s, 2), dtype=torch.int64)
         desc[:, 0] = seeds.data_ptr() + torch.arange(s, dtype=torch.int64) * (b * 4)
@@ -197,6 +236,7 @@ class TwoHopEngine:
         stage_events: optional (c_void_p * 8) of hipEvent_t recorded around the four stages."""
         if not (isinstance(seeds, torch.Tensor) and seeds.is_cuda and seeds.dtype == torch.int32 and seeds.is_contiguous()):
             seeds = as_ids(seeds, self.device)
+        seeds = self._seeds_in(seeds)
         b = seeds.shape[0]
         if b > self.max_batch:
             self._reserve(b)

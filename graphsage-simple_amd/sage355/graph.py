@@ -185,6 +185,22 @@ def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, 
     return g
 
 
+def relabel_by_degree(g):
+    """The same graph with node ids renumbered by descending degree (id 0 = the biggest hub): the rows of the feature
+    table that are gathered most often then sit next to each other in memory.  -> (graph, new_id_of_old)."""
+    deg = g.degrees()
+    order = np.argsort(-deg, kind="stable")                 # old ids in new order
+    new_of_old = np.empty(g.num_nodes, dtype=np.int64)
+    new_of_old[order] = np.arange(g.num_nodes)
+    src_old = np.repeat(np.arange(g.num_nodes, dtype=np.int64), deg)
+    src = new_of_old[src_old]
+    dst = new_of_old[g.col.astype(np.int64)]
+    key = np.sort(src * np.int64(g.num_nodes) + dst)
+    rowptr = np.zeros(g.num_nodes + 1, dtype=np.int64)
+    np.cumsum(deg[order], out=rowptr[1:])
+    return CSRGraph(rowptr, (key % g.num_nodes).astype(np.int32), g.num_nodes), new_of_old
+
+
 def truncate_nodes(g, num_nodes):
     """Keep the subgraph induced on ids < num_nodes (ogbn-products-shaped config:
     scale-22 R-MAT truncated to 2.4 M ids)."""

@@ -232,6 +232,41 @@ def test_two_hop_odd_batches_and_fanouts(b, k1, k2, concat):
     check_engine_against_oracle(graph, table, w1, w2, seeds, k1, k2, concat, False, True, seed=5)
 
 
+@pytest.mark.parametrize("concat,self_loop", [(False, False), (True, True)])
+def test_relabel_by_degree_is_the_same_engine_on_the_renumbered_graph(concat, self_loop):
+    """TwoHopEngine(relabel="degree") = the plain engine on (graph, table, seeds) renumbered by descending degree on the
+    host (sage355.graph.relabel_by_degree), bit for bit -- direct calls and graph replay -- and correct against the oracle
+    on that renumbered graph."""
+    from sage355.graph import relabel_by_degree
+    graph = rmat_graph(14, 300_000, seed=2)
+    gen = torch.Generator().manual_seed(12)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, 128, generator=gen)
+    w1 = (torch.randn(64, m * 128, generator=gen) / 12).to(DEV)
+    w2 = (torch.randn(32, m * 64, generator=gen) / 8).to(DEV)
+    seeds = np.stack([np.random.default_rng(i).choice(graph.num_nodes, 700, replace=False) for i in range(3)])
+    rowptr, col = graph.to(DEV)
+    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1, w2, 10, 20, concat=concat, agg_self_loop=self_loop, max_batch=700, relabel="degree")
+    g2, new_of_old = relabel_by_degree(graph)
+    assert np.array_equal(eng.node_order.cpu().numpy(), np.argsort(new_of_old))
+    table2 = torch.empty_like(table)
+    table2[torch.from_numpy(new_of_old)] = table
+    rp2, c2 = g2.to(DEV)
+    plain = TwoHopEngine(rp2, c2, table2.to(DEV), w1, w2, 10, 20, concat=concat, agg_self_loop=self_loop, max_batch=700)
+    sd = torch.from_numpy(seeds.astype(np.int32)).to(DEV)
+    sd2 = torch.from_numpy(new_of_old[seeds].astype(np.int32)).to(DEV)
+    want = [plain.forward(sd2[i], seed=40 + i).clone() for i in range(3)]
+    for i in range(3):
+        assert torch.equal(torch.nan_to_num(eng.forward(sd[i], seed=40 + i), nan=-7.0), torch.nan_to_num(want[i], nan=-7.0))
+    eng.set_queue(sd, [40, 41, 42])
+    out = eng.capture()
+    for i in range(3):
+        eng.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(out, nan=-7.0), torch.nan_to_num(want[i], nan=-7.0))
+    check_engine_against_oracle(g2, table2, w1.cpu(), w2.cpu(), new_of_old[seeds[0]], 10, 20, concat, self_loop, True, seed=40)
+
+
 @pytest.mark.parametrize("concat", [False, True])
 def test_two_hop_all_isolated_batch_gives_zeros_not_nan(concat):
     """aggregators.py:60-61 when NO node of the call has a neighbour: the mask has zero columns, 0/0 never happens and
