@@ -153,12 +153,12 @@ def main():
             z = np.load(os.path.join(REPO, "tests", "golden", "pubmed_topology.npz"))
             return CSRGraph(z["rowptr"], z["col"], len(z["rowptr"]) - 1)
         g_ = rmat_graph(args.scale, args.edges, seed=0, cache_dir=CACHE_DIR)
-        if args.node_order == "degree":       # ingestion option: ids renumbered by descending degree (hub rows adjacent in HBM)
-            from sage355.graph import relabel_by_degree
-            g_ = relabel_by_degree(g_)[0]
         if args.truncate:
             from sage355.graph import truncate_nodes
             g_ = truncate_nodes(g_, args.truncate)
+        if args.node_order == "degree":       # ingestion option: ids renumbered by descending degree (hub rows adjacent in HBM)
+            from sage355.graph import relabel_by_degree
+            g_ = relabel_by_degree(g_)[0]
         return g_
 
     if rank == 0:
