@@ -104,3 +104,17 @@ def test_training_split_and_batching_follow_the_reference():
     assert ref_sizes[:3] == [2167, 2039, 1911] and ref_sizes[-1] == 119 and len(ref_sizes) == 17
     plain = [min(train_num, b + bs) - b for b in range(0, train_num, bs)]
     assert plain[0] == 128 and plain[-1] == 119 and sum(plain) == train_num
+
+
+def test_relabel_by_degree_is_an_isomorphism_in_descending_degree_order():
+    """Ingestion option behind bench.py --node-order degree / TwoHopEngine(relabel="degree")."""
+    from sage355.graph import relabel_by_degree, rmat_graph
+    g = rmat_graph(11, 30_000, seed=3)
+    h, new_of_old = relabel_by_degree(g)
+    assert h.num_nodes == g.num_nodes and h.nnz == g.nnz
+    assert sorted(new_of_old.tolist()) == list(range(g.num_nodes))
+    deg = h.degrees()
+    assert (np.diff(deg) <= 0).all() and np.array_equal(deg[new_of_old], g.degrees())
+    for v in (0, 5, 77, g.num_nodes - 1):
+        assert set(new_of_old[g.neighbors(v)].tolist()) == set(h.neighbors(int(new_of_old[v])).tolist())
+        assert (np.diff(h.neighbors(int(new_of_old[v]))) > 0).all()      # rows stay sorted
