@@ -3,9 +3,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "graphsage-simple_amd"))
 import numpy as np, torch
 from sage355.engine import TwoHopEngine
-from sage355.graph import rmat_graph
+from sage355.graph import rmat_graph, relabel_by_degree
 dev = "cuda"
 g = rmat_graph(20, 16_000_000, cache_dir="/tmp/sage_cache")
+if os.environ.get("SAGE_NODE_ORDER", "degree") == "degree": g = relabel_by_degree(g)[0]
 table = torch.randn(g.num_nodes, 256, device=dev)
 rowptr, col = g.to(dev)
 eng = TwoHopEngine(rowptr, col, table, torch.randn(128, 256, device=dev) / 16, torch.randn(128, 128, device=dev) / 11, 15, 25, max_batch=4096, nan_empty=os.environ.get('SAGE_NAN', '1') == '1')
