@@ -120,6 +120,33 @@ def algorithmic_bytes(d0, h1, h2, k1dim, k2dim, b, n_s1, e1, e2, n_r1):
     return total, layer1, gather1
 
 
+def self_launch(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` from a plain shell: start N fresh rank processes (one per GPU) with
+    torch.distributed.run and relay rank 0's JSON line.  Called BEFORE this process touches the GPU (a process
+    that has initialised HIP must never exec or fork GPU work); the parent only waits.  -> exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL over dmabuf IPC (see the environment notes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in res.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if res.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank launch failed (rc={res.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return res.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +154,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -460,10 +488,29 @@ def cpu_port_baseline(graph, table, w1, w2, candidates, k1, k2, concat, budget_s
         forward(reps)              # timed: same seed -> same sets, now cached
         dt += time.perf_counter() - t0
         reps += 1
+    ratio = None
+    try:        # how far the port is from the real reference's speed, measured where the reference can be imported
+        ratio = json.load(open(os.path.join(REPO, "tests", "golden", "cpu_port_vs_reference.json")))["port_over_reference_time"]
+    except Exception:
+        pass
     return {"value": round(bs * reps / dt, 1), "unit": "embeddings/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(), "host_cores_usable": usable,
             "sample": f"{reps} forwards of B={bs} seeds on the same graph/features/weights/fanout, "
                       f"{dt:.1f} s of CPU work, oracle/ref_dense.py (dense-mask algorithm of the reference)",
-            "ms_per_forward": round(dt / reps * 1e3, 2)}
+            "ms_per_forward": round(dt / reps * 1e3, 2),
+            "port_over_reference_time": ratio,
+            "port_over_reference_source": "tests/golden/cpu_port_vs_reference.json (build container, reference imported; "
+                                          "Pubmed + R-MAT-131k workloads of SURVEY.md section 6, outputs bit-identical)"}
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 if __name__ == "__main__":

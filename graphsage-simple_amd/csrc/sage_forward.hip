@@ -143,7 +143,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     if (stages & SAGE_STAGE_SAMPLE_OUTER) {
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
-    if (int rc = sage_launch_sample(m->rowptr2, m->col2, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
+    if (int rc = sage_launch_sample(m->rowptr2, m->col2, m->num_nodes, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
                                     cnt2, (m->nan_empty && self_loop) ? any2 : nullptr, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
                                     nullptr, cursor_off, key_slot, st))
         return rc;
@@ -156,7 +156,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     //    100 us, its per-row dependent chain growing from 2 to 5 round trips.)
     const sage_resolve_t resolve{slot2, row2, batch * m->k2, self_loop ? self_slot2 : nullptr, self_row2, batch, fr.rows, fr.keys};
     SAGE_EV(2);
-    if (int rc = sage_launch_sample(m->rowptr1, m->col1, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
+    if (int rc = sage_launch_sample(m->rowptr1, m->col1, m->num_nodes, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
                                     SAGE_TAG_INNER_SELF, nbr1, cnt1, m->nan_empty ? any1 : nullptr, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
                                     &resolve, cursor_off, key_slot, st))
         return rc;

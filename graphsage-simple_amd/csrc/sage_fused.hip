@@ -334,12 +334,8 @@ __global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
                     for (int u = 0; u < INFLIGHT; ++u) {
                         const int j = j0 + u * NPI + grp;
                         const int id = __shfl(myid, min(j, m - 1), kWave);
-#ifdef SAGE_X_NOGATHER
-                        t[u] = f32x4{(float)id, 0.f, 0.f, 0.f};
-#else
                         if (col_ok && j < m) t[u] = *reinterpret_cast<const f32x4*>(a.table + (int64_t)id * a.ld + c0);
                         else t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
                     }
 #pragma unroll
                     for (int u = 0; u < INFLIGHT; ++u) acc += t[u];
@@ -372,11 +368,7 @@ __global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
                     const f32x4 av = *reinterpret_cast<const f32x4*>(abase + 16 * q);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-#ifdef SAGE_X_NOMFMA
-                        acc[t] += av[t] * breg[chunk * (KP / 4) + 4 * q + t];
-#else
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], breg[chunk * (KP / 4) + 4 * q + t], acc, 0, 0, 0);
-#endif
                 }
             }
             const int col = n0 + i16;

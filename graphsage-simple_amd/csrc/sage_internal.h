@@ -17,7 +17,7 @@ struct sage_finish_t {
 };
 // Device-side row count = min(*n_dev + n_off, n).
 
-int sage_launch_sample(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t n, const int32_t* n_dev,
+int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_nodes, const int32_t* nodes, int32_t n, const int32_t* n_dev,
                        int32_t k, uint64_t seed, uint32_t tag, int32_t tag_self_rows, uint32_t tag_self,
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
                        int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* queue_model,

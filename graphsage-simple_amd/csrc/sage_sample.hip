@@ -84,7 +84,7 @@ void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
 
 // Internal launcher shared with sage_forward.hip (tag_self_rows: rows [0, tag_self_rows)
 // draw from stream `tag_self` -- the concat encoder's second enc1 call on the seeds).
-int sage_launch_sample(const int64_t* rowptr, const int32_t* col, const int32_t* nodes, int32_t n, const int32_t* n_dev,
+int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_nodes, const int32_t* nodes, int32_t n, const int32_t* n_dev,
                        int32_t k, uint64_t seed, uint32_t tag, int32_t tag_self_rows, uint32_t tag_self,
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
                        int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* qm, int nodes_from_batch,
@@ -93,7 +93,7 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, const int32_t*
     if (n == 0) return SAGE_OK;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const BatchSrc bs{qm ? qm->queue : nullptr, qm ? qm->queue_cursor : nullptr, qm ? qm->queue_len : 0, nodes_from_batch, nodes_copy,
-                      cursor_off, key_slot};
+                      cursor_off, key_slot, (int)num_nodes};
     ResolveJob rj{};
     if (resolve) rj = ResolveJob{resolve->slots, resolve->rows_out, resolve->n_slots, resolve->self_slots, resolve->self_rows_out,
                                  resolve->n_self, resolve->hash_rows, resolve->hash_keys};
@@ -135,7 +135,7 @@ extern "C" int sage_sample_neighbors(const int64_t* rowptr, const int32_t* col, 
         SAGE_REQUIRE(nbr_slot, "sample_neighbors: frontier given but nbr_slot is NULL");
         SAGE_REQUIRE(!insert_self || self_slot, "sample_neighbors: insert_self needs self_slot");
     }
-    return sage_launch_sample(rowptr, col, nodes, n, n_dev, k, seed, tag, 0, tag, nbr, cnt, any_nonempty, frontier, insert_self,
+    return sage_launch_sample(rowptr, col, num_nodes, nodes, n, n_dev, k, seed, tag, 0, tag, nbr, cnt, any_nonempty, frontier, insert_self,
                               nbr_slot, self_slot, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
@@ -154,7 +154,7 @@ extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int3
     const int32_t* no32 = nullptr;
     launch_by_fanout<false, true>(k, n, (hipStream_t)stream, no64, no32, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt,
                                   (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, fd, self_nodes ? 1 : 0, nbr_slot,
-                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr}, 0, ResolveJob{});
+                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0}, 0, ResolveJob{});
     SAGE_CHECK_LAUNCH("frontier_insert_kernel");
     return SAGE_OK;
 }

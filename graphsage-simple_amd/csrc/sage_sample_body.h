@@ -17,6 +17,9 @@ struct BatchSrc {
     int cursor_off;           // descriptor = queue[(*cursor + cursor_off) % len]  (pipelined forwards sample one batch ahead)
     uint64_t* key_slot;       // nullable: the outer hop leaves the sampler key here, the inner hop takes it from here
                               // instead of the queue (it then never reads the cursor, which another batch's last kernel advances)
+    int num_nodes;            // ids outside [0, num_nodes) are treated as isolated nodes (degree 0): the reference raises
+                              // IndexError for them (nn.Embedding lookup); a device kernel must not walk rowptr[] with them.
+                              // 0 = no check (callers that produced the ids themselves)
 };
 
 struct FrontierDev {
@@ -110,8 +113,10 @@ __device__ __forceinline__ void sample_block(
         if (active) {
             v = nodes[r];
             if (bs.nodes_copy && gl == 0) bs.nodes_copy[r] = v;
-            s = rowptr[v];
-            deg = rowptr[v + 1] - s;
+            if (bs.num_nodes == 0 || (uint32_t)v < (uint32_t)bs.num_nodes) {
+                s = rowptr[v];
+                deg = rowptr[v + 1] - s;
+            }
             c = (int)min(deg, (int64_t)k);
         }
         const bool floyd = active && deg > (int64_t)k;

@@ -19,10 +19,17 @@ two-layer stack from it unchanged (model.py:218-222).  Underneath:
 
 Sampling: the device sampler draws k distinct uniform neighbours per node
 (all of them when deg < k), the reference's rule (aggregators.py:42-46), from a
-counter-based generator.  Each ``forward`` takes ONE 64-bit value from Python's
-global ``random`` as its key, so ``random.seed(s)`` (model.py:193) still makes a
-run reproducible, but the sets differ from the reference's for the same seed.
+counter-based generator.  The two device-sampler paths (``_forward_two_hop``,
+``_forward_table``) take ONE 64-bit value from Python's global ``random`` per
+``forward`` as the key, so ``random.seed(s)`` (model.py:193) still makes a run
+reproducible, but (a) the sets differ from the reference's for the same seed and
+(b) the global stream is advanced by one ``getrandbits(64)`` per call instead of
+one ``random.sample`` per node -- a program that interleaves its own draws from
+``random`` sees different values than under the reference.  Only the strict path
+(``MeanAggregator.forward`` / ``_forward_generic``) consumes the stream call for
+call as the reference does.
 """
+import collections
 import random
 
 import numpy as np
@@ -37,14 +44,41 @@ from .graph import csr_from_adj_lists
 
 SIGMOID_INITIALIZERS = ("node_degree", "shared", "pagerank")   # encoders.py:58
 
-_csr_cache = {}
+_CSR_CACHE_MAX = 8            # adjacency objects kept (LRU): both layers of a model share one, a process holds a few models
+_CSR_CHECK_MAX_NODES = 200_000  # adjacencies up to this many keys are re-fingerprinted on every call
+_csr_cache = collections.OrderedDict()
+
+
+def _fingerprint(adj_lists):
+    """(non-empty sets, total degree): detects an adjacency mutated in place after first use.  Empty sets that the
+    reference's defaultdict inserts on a miss (encoders.py:47) do not change it.  O(N) in Python, so only computed for
+    small adjacencies; a large one is FROZEN at first use (call invalidate_adjacency(adj_lists) after editing it)."""
+    if len(adj_lists) > _CSR_CHECK_MAX_NODES:
+        return None
+    nonempty = total = 0
+    for s in adj_lists.values():
+        n = len(s)
+        total += n
+        nonempty += n > 0
+    return nonempty, total
+
+
+def invalidate_adjacency(adj_lists=None):
+    """Drop the cached device CSR of `adj_lists` (all of them when None)."""
+    if adj_lists is None:
+        _csr_cache.clear()
+    else:
+        _csr_cache.pop(id(adj_lists), None)
 
 
 def _device_csr(adj_lists, num_nodes_hint, device):
-    """dict-of-sets -> CSR in HBM, cached per adjacency object (both layers share one, model.py:219-222)."""
+    """dict-of-sets -> CSR in HBM, cached per adjacency object (both layers share one, model.py:219-222).
+    The reference re-reads the dict on every call; here the conversion is cached and revalidated by a fingerprint."""
     key = id(adj_lists)
+    fp = _fingerprint(adj_lists)
     hit = _csr_cache.get(key)
-    if hit is not None and hit[0] is adj_lists:
+    if hit is not None and hit[0] is adj_lists and hit[3] == fp and hit[4] == num_nodes_hint:
+        _csr_cache.move_to_end(key)
         return hit[1], hit[2]
     g = csr_from_adj_lists(adj_lists, None)
     if num_nodes_hint and g.num_nodes < num_nodes_hint:
@@ -54,7 +88,10 @@ def _device_csr(adj_lists, num_nodes_hint, device):
     rowptr, col = g.to(device)
     if col.numel() == 0:
         col = torch.zeros(1, dtype=torch.int32, device=device)
-    _csr_cache[key] = (adj_lists, rowptr, col)
+    _csr_cache[key] = (adj_lists, rowptr, col, fp, num_nodes_hint)
+    _csr_cache.move_to_end(key)
+    while len(_csr_cache) > _CSR_CACHE_MAX:
+        _csr_cache.popitem(last=False)
     return rowptr, col
 
 
@@ -161,7 +198,7 @@ class Encoder(nn.Module):
         dev = torch.device("cuda")
         table = self._on_device(self.features.weight, "table")
         rowptr, col = _device_csr(self.adj_lists, table.shape[0], dev)
-        ids = ops.as_ids(nodes, dev)
+        ids = ops.as_ids(nodes, dev, table.shape[0])
         any_nonempty = torch.zeros(1, dtype=torch.int32, device=dev)
         nbr, cnt, _, _ = ops.sample_neighbors(rowptr, col, ids, self.num_sample, random.getrandbits(64), ops.TAG_INNER,
                                               any_nonempty=any_nonempty)

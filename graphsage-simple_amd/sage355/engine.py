@@ -158,6 +158,8 @@ class TwoHopEngine:
         s, b = seeds.shape
         if len(rng_seeds) != s:
             raise native.SageError("set_queue: one sampler key per batch")
+        if seeds.numel() and (int(seeds.min()) < 0 or int(seeds.max()) >= self.num_nodes):     # one sync, outside any timed loop
+            raise native.SageError(f"set_queue: seed id outside [0, {self.num_nodes})")
         seeds = self._seeds_in(seeds).contiguous()
         self._reserve(b)
         desc = torch.empty((s, 2), dtype=torch.int64)
@@ -235,7 +237,7 @@ class TwoHopEngine:
         `seed` keys the sampler: the sets are a pure function of (seed, node id, hop).
         stage_events: optional (c_void_p * 8) of hipEvent_t recorded around the four stages."""
         if not (isinstance(seeds, torch.Tensor) and seeds.is_cuda and seeds.dtype == torch.int32 and seeds.is_contiguous()):
-            seeds = as_ids(seeds, self.device)
+            seeds = as_ids(seeds, self.device, self.num_nodes)
         seeds = self._seeds_in(seeds)
         b = seeds.shape[0]
         if b > self.max_batch:

@@ -36,12 +36,29 @@ def _row_major(t, name):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1))
 
 
-def as_ids(nodes, device):
-    """list / numpy / tensor of node ids -> int32 device tensor (encoders.py:40-47 accepts all three)."""
-    if isinstance(nodes, torch.Tensor):
-        return nodes.to(device=device, dtype=torch.int32).contiguous()
+def check_id_range(ids64, num_nodes, what="node ids"):
+    """Host-side range check of ids that arrived from the host (numpy int64 array).  The reference fails safely for a
+    bad id (IndexError from the nn.Embedding lookup, encoders.py:50 / aggregators.py:65); a device kernel would read
+    rowptr[] out of bounds, so the check happens here, BEFORE the int32 cast can wrap a large id into range."""
+    if num_nodes is None or ids64.size == 0:
+        return
+    lo, hi = int(ids64.min()), int(ids64.max())
+    if lo < 0 or hi >= int(num_nodes):
+        raise native.SageError(f"{what}: id {lo if lo < 0 else hi} outside [0, {int(num_nodes)})")
+
+
+def as_ids(nodes, device, num_nodes=None):
+    """list / numpy / tensor of node ids -> int32 device tensor (encoders.py:40-47 accepts all three).
+    num_nodes: ids that come from the HOST are range-checked against it (SageError); device-resident ids are not
+    (that would be a host sync per call) -- the sampler kernels treat an out-of-range id as an isolated node instead."""
     import numpy as np
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(nodes, dtype=np.int64).astype(np.int32))).to(device)
+    if isinstance(nodes, torch.Tensor):
+        if not nodes.is_cuda:
+            check_id_range(nodes.detach().to(torch.int64).numpy(), num_nodes)
+        return nodes.to(device=device, dtype=torch.int32).contiguous()
+    ids64 = np.asarray(nodes, dtype=np.int64)
+    check_id_range(ids64, num_nodes)
+    return torch.from_numpy(np.ascontiguousarray(ids64.astype(np.int32))).to(device)
 
 
 def next_pow2(x):

@@ -5,6 +5,11 @@ Kept from the reference: the classifier (weight [C, embed_dim], xavier, scores =
 CrossEntropyLoss), the 10 / 10 / 80 test / val / train split of np.random.permutation
 (model.py:229-234), SGD lr = 0.7 (model.py:237), random.shuffle of the train list per epoch,
 micro/macro F1 on the validation split (model.py:256-258), mean batch time (model.py:259).
+The per-epoch shuffle draws from a generator of its OWN (`random.Random(seed)`), not from Python's
+global `random`: the neighbour samplers consume the global stream by a shard-dependent amount, so
+data-parallel ranks sharing it would hold different permutations of `train` and `shard_batch` would
+slice overlapping / incomplete shards.  With a private generator every rank holds the same
+permutation and the union of the shards is exactly the global batch.
 Deliberately different: batches are plain `batch_size` slices by default; `ref_batching=True`
 reproduces the reference's `train[batch:max(train_num, batch+batch_size)]` descending batches
 (model.py:244, a `max` where `min` was meant).  Everything stays on the GPU; with world_size > 1
@@ -60,7 +65,7 @@ def build_model(feat_data, adj_lists, num_classes, hidden1=50, hidden2=128, num_
 
 
 def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, batch_size=128, ref_batching=False, lr=0.7,
-                 model=None, verbose=True, sample_seed=None, return_model=False, **model_kwargs):
+                 model=None, verbose=True, sample_seed=None, return_model=False, on_batch=None, **model_kwargs):
     """-> dict(f1_micro, f1_macro, mean_batch_time, losses).  Mirrors run_model (model.py:184-259).
     `seed` seeds numpy (the split) and Python's random (shuffles + neighbour sampling) as model.py:192-193
     does; `sample_seed` reseeds only Python's random, to vary the sampling stream on a fixed split."""
@@ -78,14 +83,17 @@ def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, ba
     val = rand_indices[int(0.1 * num_nodes):int(0.2 * num_nodes)]
     train = list(rand_indices[int(0.2 * num_nodes):])
     optimizer = torch.optim.SGD(params, lr=lr)
+    shuffler = random.Random(seed)        # identical on every rank, untouched by neighbour sampling
     labels_t = torch.as_tensor(labels, dtype=torch.int64).squeeze(-1)
     times, losses = [], []
     for _ in range(epochs):
-        random.shuffle(train)
+        shuffler.shuffle(train)
         for batch in range(0, len(train), batch_size):
             hi = max(len(train), batch + batch_size) if ref_batching else min(len(train), batch + batch_size)
             batch_nodes = train[batch:hi]
             mine = dist.shard_batch(batch_nodes, rank, world)
+            if on_batch is not None:
+                on_batch(batch_nodes, mine)       # test hook: which nodes this rank was given
             start = time.time()
             optimizer.zero_grad()
             if len(mine):

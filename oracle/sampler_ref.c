@@ -21,8 +21,10 @@
  *   nbr[r*k+j] = col[rowptr[v] + j],      cnt[r] = deg    (deg <= k), rest -1
  *
  * Parity status of the stream itself: "parity unpinned" by construction (the
- * reference has no counterpart); tests/test_sampler.py pins its statistics
- * and the device kernel bit-for-bit against this file.
+ * reference has no counterpart).  tests/test_sampler_kat.py checks the Philox
+ * block function against the Random123 known-answer vectors and the Floyd walk
+ * against a pure-Python restatement (CPU); tests/test_gpu_ops.py pins the
+ * device kernel bit-for-bit against this file and tests its statistics.
  */
 #include <stdint.h>
 

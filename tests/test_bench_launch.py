@@ -1,0 +1,45 @@
+"""`python bench.py --gpus N` must be runnable from a plain shell: the parent starts N rank
+processes with torch.distributed.run before touching the GPU and relays rank 0's JSON line.  CPU test of that
+launcher with a stand-in rank script (gloo, world_size 2); the real thing runs in tests/test_gpu_forward.py."""
+import json
+import os
+import sys
+import textwrap
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+RANK_SCRIPT = textwrap.dedent("""
+    import json, os, sys
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(dist.get_rank() + 1)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if "--fail" in sys.argv and dist.get_rank() == 1:
+        sys.exit(3)
+    print("noise from rank", dist.get_rank(), flush=True)
+    if dist.get_rank() == 0:
+        print(json.dumps({"metric": "m", "n_gpus": dist.get_world_size(), "max": t.item(), "argv": sys.argv[1:]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_self_launch_relays_rank0_line(tmp_path, capfd):
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    rc = bench.self_launch(2, ["--gpus", "2", "--steps", "3"], script=str(script), timeout=300)
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["max"] == 2.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+
+
+def test_self_launch_fails_loudly_when_a_rank_dies(tmp_path, capfd):
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    rc = bench.self_launch(2, ["--fail"], script=str(script), timeout=300)
+    assert rc != 0
+    assert capfd.readouterr().out.strip() == ""

@@ -66,6 +66,58 @@ def test_two_rank_gloo_data_parallel_path(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+class _RandomHungryModel(torch.nn.Module):
+    """CPU stand-in for SupervisedGraphSage: like the neighbour samplers it draws from Python's GLOBAL `random`,
+    by an amount that depends on the shard it was handed (so ranks de-synchronise that stream at once)."""
+
+    def __init__(self, num_nodes, classes):
+        super().__init__()
+        self.emb = torch.nn.Embedding(num_nodes, classes)
+
+    def forward(self, nodes):
+        import random
+        for _ in range(int(sum(int(n) for n in nodes) % 17) + 1):
+            random.getrandbits(64)
+        return self.emb(torch.as_tensor(np.asarray(nodes), dtype=torch.int64))
+
+
+def _train_worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_from_env(backend="gloo")
+    from sage355.train import run_training
+    n, classes = 203, 3
+    torch.manual_seed(0)
+    model = _RandomHungryModel(n, classes)
+    labels = np.random.default_rng(0).integers(0, classes, (n, 1))
+    seen = []
+    # per-rank sampler streams differ (tests/test_gpu_train.py seeds them per rank); the shuffle must not care
+    run_training(np.zeros((n, 4), np.float32), labels, None, classes, seed=3, epochs=3, batch_size=32, model=model, verbose=False,
+                 sample_seed=50 + rank, on_batch=lambda batch, mine: seen.append(([int(x) for x in batch], [int(x) for x in mine])))
+    everyone = [None] * world
+    torch.distributed.all_gather_object(everyone, seen)
+    assert len(seen) >= 3 * 5
+    for step in range(len(seen)):
+        batches = [everyone[r][step][0] for r in range(world)]
+        shards = [everyone[r][step][1] for r in range(world)]
+        assert all(b == batches[0] for b in batches), f"step {step}: ranks hold different permutations of the train list"
+        assert sum(shards, []) == batches[0], f"step {step}: shards do not tile the global batch"
+        assert len(set(sum(shards, []))) == len(batches[0])
+    # the permutation really changes from epoch to epoch (it is a shuffle, not a fixed order)
+    per_epoch = len(seen) // 3
+    assert everyone[0][0][0] != everyone[0][per_epoch][0]
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_training_shards_tile_every_global_batch(tmp_path):
+    """the epoch shuffle used Python's global `random`, which the samplers consume by a shard-dependent
+    amount -> ranks held different permutations.  Three epochs, two ranks, different sampler seeds per rank."""
+    port = free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
 def test_shard_bounds_cover_every_unit_once():
     for n in (0, 1, 7, 4096, 4097):
         for world in (1, 2, 3, 8):

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from sage355 import graph as G
 from sage355.datasets import standin_citation
@@ -118,3 +119,59 @@ def test_relabel_by_degree_is_an_isomorphism_in_descending_degree_order():
     for v in (0, 5, 77, g.num_nodes - 1):
         assert set(new_of_old[g.neighbors(v)].tolist()) == set(h.neighbors(int(new_of_old[v])).tolist())
         assert (np.diff(h.neighbors(int(new_of_old[v]))) > 0).all()      # rows stay sorted
+
+
+def test_host_ids_are_range_checked_before_the_int32_cast():
+    """a negative / too large / wrapping id must raise on the host (the reference raises IndexError from
+    the nn.Embedding lookup), never reach a kernel that walks rowptr[] with it."""
+    from sage355 import native, ops
+    ok = np.array([0, 5, 99], dtype=np.int64)
+    ops.check_id_range(ok, 100)
+    ops.check_id_range(np.zeros(0, np.int64), 100)
+    ops.check_id_range(ok, None)
+    for bad in ([-1, 3], [100], [2 ** 32 + 5]):          # the last one would wrap to 5 under a blind int32 cast
+        with pytest.raises(native.SageError):
+            ops.check_id_range(np.asarray(bad, dtype=np.int64), 100)
+    with pytest.raises(native.SageError):
+        ops.as_ids([3, 2 ** 31], "cpu", 10)
+    assert ops.as_ids([3, 9], "cpu", 10).dtype == torch.int32
+
+
+def test_adjacency_cache_detects_in_place_mutation_and_is_bounded(monkeypatch):
+    """the device-CSR cache was keyed by id(adj_lists) only (stale after an in-place edit, never evicted)."""
+    from collections import defaultdict
+    from sage355 import encoders
+    calls = []
+
+    class FakeGraph:
+        def __init__(self, adj):
+            self.num_nodes = (max(adj) + 1) if adj else 0
+            self.rowptr = np.zeros(self.num_nodes + 1, np.int64)
+
+        def to(self, device):
+            return torch.zeros(self.num_nodes + 1, dtype=torch.int64), torch.zeros(1, dtype=torch.int32)
+
+    def fake_csr(adj, n):
+        calls.append(sum(len(s) for s in adj.values()))
+        return FakeGraph(adj)
+
+    monkeypatch.setattr(encoders, "csr_from_adj_lists", fake_csr)
+    encoders.invalidate_adjacency()
+    adj = defaultdict(set, {0: {1}, 1: {0, 2}, 2: {1}})
+    encoders._device_csr(adj, 3, "cpu")
+    encoders._device_csr(adj, 3, "cpu")
+    assert calls == [4]                          # second call is a cache hit
+    adj[7]                                       # the reference's defaultdict inserts an empty set on a miss: same graph
+    encoders._device_csr(adj, 3, "cpu")
+    assert calls == [4]
+    adj[0].add(2)
+    adj[2].add(0)                                # edited in place: must be rebuilt
+    encoders._device_csr(adj, 3, "cpu")
+    assert calls == [4, 6]
+    encoders.invalidate_adjacency(adj)
+    encoders._device_csr(adj, 3, "cpu")
+    assert calls == [4, 6, 6]
+    keep = [defaultdict(set, {0: {i + 1}}) for i in range(encoders._CSR_CACHE_MAX + 3)]
+    for a in keep:
+        encoders._device_csr(a, 0, "cpu")
+    assert len(encoders._csr_cache) == encoders._CSR_CACHE_MAX
