@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <string.h>
 
-#include "sage_common.h"
+#include <stdlib.h>
+
+#include "sage_internal.h"
 
 static thread_local char g_err[512] = "";
 
@@ -16,3 +18,23 @@ void sage_set_error(const char* fmt, ...) {
 extern "C" int sage_abi_version(void) { return SAGE_ABI_VERSION; }
 extern "C" const char* sage_last_error(void) { return g_err; }
 extern "C" const char* sage_build_arch(void) { return "gfx950"; }
+
+static int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const long x = strtol(v, nullptr, 10);
+    return (int)(x < lo ? lo : x > hi ? hi : x);
+}
+
+const sage_tunables_t& sage_tunables() {
+    static const sage_tunables_t t = [] {
+        sage_tunables_t x;
+        x.gather_blocks_per_cu = env_int("SAGE_G_PER_CU", 8, 1, 8);
+        x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU * 3 / 4, 32, 512);
+        const int so = env_int("SAGE_SO_THREADS", 1024, 256, 1024);
+        x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
+        x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);
+        return x;
+    }();
+    return t;
+}

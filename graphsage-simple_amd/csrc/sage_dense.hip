@@ -409,10 +409,7 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     // flight it is worth 3 us per forward -- a block holds 344 of a SIMD's 512 VGPRs and 117 KB of LDS for its whole life,
     // and the other batch's latency-bound kernels get the remaining CUs to themselves (same-box A/B: 184-224 blocks
     // 81.3-81.9 us, 256 blocks 84.2, 160 blocks 83.1).
-#ifndef SAGE_DENSE_BLOCKS
-#define SAGE_DENSE_BLOCKS (kNumCU * 3 / 4)
-#endif
-    const int grid = min(sage_cdiv(a.n, 32), SAGE_DENSE_BLOCKS);
+    const int grid = min(sage_cdiv(a.n, 32), sage_tunables().dense_blocks);
     hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP>), dim3(grid), dim3(512), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
     return SAGE_OK;

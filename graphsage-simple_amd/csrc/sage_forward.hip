@@ -230,6 +230,12 @@ extern "C" int sage_forward2_stages(const sage_model_t* m, void* workspace, size
     return forward2_impl(m, workspace, workspace_bytes, nullptr, batch, 0, out, ldo, stream, nullptr, stages, cursor_offset, true);
 }
 
+// A subset of the forward's launches with the seeds and the sampler key taken from the call (sage_pipe.hip: one call per role stream)
+int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
+                                uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream) {
+    return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, (sage_stream_t)stream, nullptr, stages, 0, false);
+}
+
 // gather(batch at the cursor, workspace `cur`) + outer sample(next batch, workspace `next`) as ONE launch (sage_pipeline.hip)
 extern "C" int sage_forward2_gather_sample(const sage_model_t* m, void* ws_cur, void* ws_next, size_t workspace_bytes, int32_t batch,
                                            int32_t cursor_offset, sage_stream_t stream) {

@@ -395,7 +395,7 @@ int launch_tile16(const FusedArgs& a, hipStream_t st) {
 #endif
     constexpr int INFLIGHT = CONCAT ? 7 : SAGE_T16_INFLIGHT;
     const int tiles = sage_cdiv(a.n, 16);
-    const int grid = min(tiles, 2 * kNumCU);
+    const int grid = min(tiles, sage_tunables().tile16_grid);
     hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT>), dim3(grid), dim3(1024), 0, st, a);
     SAGE_CHECK_LAUNCH("layer_tile16_kernel");
     return SAGE_OK;

@@ -117,9 +117,6 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
                             hipStream_t st) {
     if (n == 0) return SAGE_OK;
     if (sage_gather_is_sliced(dim, ld, ldo, table, out, n, k)) {
-#ifndef SAGE_G_PER_CU
-#define SAGE_G_PER_CU 8
-#endif
         // 256-B slices (16 lanes; 512-B rows: 29.1 us as two slices vs 32.5 us as one).  A narrow row that does not end
         // on a slice boundary is ONE slice of 32 lanes instead (two neighbours per wave-instruction): 400-B rows
         // (config 5) 40.5 us vs 45.5 us as a 256-B + a 144-B slice
@@ -132,7 +129,7 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
 #endif
         (void)kForce;
         const int nslice = sage_cdiv(dim, sl * 4);
-        const int blocks = nslice * (kNumCU * SAGE_G_PER_CU / nslice);
+        const int blocks = nslice * (kNumCU * sage_tunables().gather_blocks_per_cu / nslice);
         if (sl == 32)
             hipLaunchKernelGGL(gather_mean_sliced_kernel<32>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
                                n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);

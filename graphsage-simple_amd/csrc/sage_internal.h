@@ -55,6 +55,19 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
                             sage_finish_t fin, hipStream_t st);
 
+int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
+                                uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream);
+
+// Launch-shape tunables, read ONCE from the environment (A/B runs on one box without rebuilding; defaults are the
+// measured optima recorded in DESIGN.md).  Every value is clamped to a safe range.
+struct sage_tunables_t {
+    int gather_blocks_per_cu;     // SAGE_G_PER_CU        sliced gather: 256-thread blocks per CU (1..8), default 8
+    int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 192
+    int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 1024
+    int tile16_grid;              // SAGE_T16_GRID        layer-2 tile16 kernel: max blocks (64..1024), default 512
+};
+const sage_tunables_t& sage_tunables();
+
 // Narrowest layer that takes the split form (column-sliced gather + dense contraction) instead of the one-launch layer.
 #ifndef SAGE_SPLIT_MIN_DIM
 #define SAGE_SPLIT_MIN_DIM 64

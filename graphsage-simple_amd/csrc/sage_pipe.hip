@@ -1,0 +1,210 @@
+// Role pipeline: consecutive 2-hop forwards software-pipelined over ROLE STREAMS.
+//
+// One forward is a chain of five dependent launches (sage_forward.hip); enqueued on one stream it pays a kernel
+// boundary between every pair and leaves the latency-bound stages (samplers, layer 2) alone on the chip.  Here each
+// STAGE of the forward has a HIP stream of its own and consecutive batches flow through them like through an
+// assembly line, over `depth` workspaces:
+//
+//     stream S :  sample(b+2)        outer hop + frontier, inner hop          (dependent round trips)
+//     stream G :  gather(b+1)        layer-1 column-sliced gather             (fabric / HBM bound: the pacemaker)
+//     stream D :  contract(b)        layer-1 split-bf16 MFMA contraction      (matrix pipe)
+//     stream L :  layer2(b-1)        layer-2 gather + MFMA, workspace release
+//
+// so that what is on the critical path is one stage, not the sum of five, and every stream's own boundary
+// (kernel fill/drain, L2 write-back) is covered by the other streams' kernels.  Dependencies are hipEvents:
+// S(b) -> G(b) -> D(b) -> L(b) -> S(b + depth) (workspace reuse).  Streams may coincide (an event between two
+// roles on the same stream is skipped), so {S,G,D,L} = one stream degenerates to sage_forward2.
+// Results are bit-identical to sage_forward2 on the same (seeds, key): same kernels, same workspaces' layout.
+// The reference has no counterpart: model.py:240-252 runs one batch at a time on the host.
+#include <new>
+
+#include "sage_internal.h"
+
+struct sage_pipe {
+    sage_model_t model;
+    int32_t batch;
+    int32_t depth;
+    void* ws[SAGE_PIPE_MAX_DEPTH];
+    size_t ws_bytes;
+    hipStream_t st[4];                                  // S, G, D, L
+    hipEvent_t ev[4][SAGE_PIPE_MAX_DEPTH];              // [role][slot]: role's work on the slot's batch is enqueued
+    hipEvent_t ev_fork;
+    uint64_t submitted;
+    bool split;                                         // layer 1 runs as gather + contraction (else one launch on D)
+};
+
+namespace {
+enum { RS = 0, RG = 1, RD = 2, RL = 3 };
+
+int wait_on(sage_pipe* p, int consumer, int producer, int slot) {
+    if (p->st[consumer] == p->st[producer]) return SAGE_OK;          // stream order already says it
+    if (hipStreamWaitEvent(p->st[consumer], p->ev[producer][slot], 0) != hipSuccess) {
+        sage_set_error("pipe: hipStreamWaitEvent failed");
+        return SAGE_ELAUNCH;
+    }
+    return SAGE_OK;
+}
+int record(sage_pipe* p, int role, int slot, bool needed) {
+    if (!needed) return SAGE_OK;
+    if (hipEventRecord(p->ev[role][slot], p->st[role]) != hipSuccess) {
+        sage_set_error("pipe: hipEventRecord failed");
+        return SAGE_ELAUNCH;
+    }
+    return SAGE_OK;
+}
+}  // namespace
+
+extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t depth, void* const* workspaces, size_t workspace_bytes,
+                                const sage_stream_t* streams, sage_pipe_t** out) {
+    SAGE_REQUIRE(m && workspaces && streams && out, "pipe_create: NULL argument");
+    SAGE_REQUIRE(!m->queue, "pipe_create: the pipeline takes seeds and keys per submit, not from a batch queue");
+    SAGE_REQUIRE(depth >= 1 && depth <= SAGE_PIPE_MAX_DEPTH, "pipe_create: depth = %d outside [1, %d]", depth, SAGE_PIPE_MAX_DEPTH);
+    SAGE_REQUIRE(batch >= 1 && (m->ws_batch == 0 || batch <= m->ws_batch), "pipe_create: batch = %d", batch);
+    sage_ws_layout_t L;
+    if (int rc = sage_forward2_layout(m, m->ws_batch ? m->ws_batch : batch, &L)) return rc;
+    if (L.total_bytes > workspace_bytes) {
+        sage_set_error("pipe_create: workspace %zu bytes < %zu needed", workspace_bytes, L.total_bytes);
+        return SAGE_ENOSPACE;
+    }
+    for (int i = 0; i < depth; ++i) {
+        SAGE_REQUIRE(workspaces[i] && sage_aligned(workspaces[i], 256), "pipe_create: workspace %d NULL or not 256-byte aligned", i);
+        for (int j = 0; j < i; ++j) SAGE_REQUIRE(workspaces[i] != workspaces[j], "pipe_create: workspaces %d and %d coincide", i, j);
+    }
+    sage_pipe* p = new (std::nothrow) sage_pipe();
+    SAGE_REQUIRE(p, "pipe_create: out of host memory");
+    p->model = *m;
+    p->batch = batch;
+    p->depth = depth;
+    p->ws_bytes = workspace_bytes;
+    p->submitted = 0;
+    p->split = L.layer1_split != 0;
+    for (int i = 0; i < depth; ++i) p->ws[i] = workspaces[i];
+    for (int r = 0; r < 4; ++r) p->st[r] = (hipStream_t)streams[r];
+    for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < depth; ++i) p->ev[r][i] = nullptr;
+    p->ev_fork = nullptr;
+    if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        sage_set_error("pipe_create: hipEventCreate failed");
+        delete p;
+        return SAGE_ELAUNCH;
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < depth; ++i)
+            if (hipEventCreateWithFlags(&p->ev[r][i], hipEventDisableTiming) != hipSuccess) {
+                sage_set_error("pipe_create: hipEventCreate failed");
+                sage_pipe_destroy(p);
+                return SAGE_ELAUNCH;
+            }
+    *out = p;
+    return SAGE_OK;
+}
+
+extern "C" int sage_pipe_destroy(sage_pipe_t* p) {
+    if (!p) return SAGE_OK;
+    for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < p->depth; ++i)
+            if (p->ev[r][i]) (void)hipEventDestroy(p->ev[r][i]);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    delete p;
+    return SAGE_OK;
+}
+
+extern "C" int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2) {
+    SAGE_REQUIRE(p && w1 && w2, "pipe_update_weights: NULL argument");
+    p->model.w1 = w1;
+    p->model.w2 = w2;
+    return SAGE_OK;
+}
+
+// One batch through the four role streams.  `first_in_segment`: no earlier submit of this pipe is outstanding on the
+// slot (a fresh pipe, or the first `depth` submits inside a stream capture, where the captured graph itself orders
+// replays): the workspace-release wait is skipped.
+static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot) {
+    const int slot = (int)(p->submitted % (uint64_t)p->depth);
+    const sage_model_t* m = &p->model;
+    void* ws = p->ws[slot];
+    // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
+    if (!fresh_slot)
+        if (int rc = wait_on(p, RS, RL, slot)) return rc;
+    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0,
+                                             SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
+        return rc;
+    if (int rc = record(p, RS, slot, p->st[RG] != p->st[RS])) return rc;
+    // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
+    if (int rc = wait_on(p, RG, RS, slot)) return rc;
+    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG])) return rc;
+    if (int rc = record(p, RG, slot, p->st[RD] != p->st[RG])) return rc;
+    // D: the contraction (or the whole fused layer 1)
+    if (int rc = wait_on(p, RD, RG, slot)) return rc;
+    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
+    if (int rc = record(p, RD, slot, p->st[RL] != p->st[RD])) return rc;
+    // L: layer 2; afterwards the workspace is clean again
+    if (int rc = wait_on(p, RL, RD, slot)) return rc;
+    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, out, ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
+    if (int rc = record(p, RL, slot, p->st[RS] != p->st[RL])) return rc;
+    ++p->submitted;
+    return SAGE_OK;
+}
+
+extern "C" int sage_pipe_submit(sage_pipe_t* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo) {
+    SAGE_REQUIRE(p && seeds && out, "pipe_submit: NULL argument");
+    SAGE_REQUIRE(ldo >= p->model.h2, "pipe_submit: ldo = %lld < h2", (long long)ldo);
+    return submit_one(p, seeds, key, out, ldo, p->submitted < (uint64_t)p->depth);
+}
+
+// n batches in one call (one host loop, no per-batch crossing of the language boundary): batch i takes
+// seeds + i*seed_stride, keys[i] and writes out + (i % out_slots) * out_stride.
+// segment_start != 0: treat the first `depth` batches as having fresh slots (use inside a stream capture, after
+// sage_pipe_join of the previous segment).
+extern "C" int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64_t seed_stride, const uint64_t* keys_host, int32_t n,
+                                     float* out, int64_t ldo, int64_t out_stride, int32_t out_slots, int32_t segment_start) {
+    SAGE_REQUIRE(p && seeds && keys_host && out, "pipe_submit_many: NULL argument");
+    SAGE_REQUIRE(n >= 0 && out_slots >= 1 && seed_stride >= 0 && out_stride >= 0, "pipe_submit_many: n = %d, out_slots = %d", n, out_slots);
+    SAGE_REQUIRE(ldo >= p->model.h2, "pipe_submit_many: ldo = %lld < h2", (long long)ldo);
+    SAGE_REQUIRE(out_slots >= p->depth || out_stride == 0, "pipe_submit_many: %d output slots for %d batches in flight", out_slots, p->depth);
+    const uint64_t base = segment_start ? p->submitted : 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const bool fresh = p->submitted - base < (uint64_t)p->depth && (segment_start || p->submitted < (uint64_t)p->depth);
+        if (int rc = submit_one(p, seeds + (int64_t)i * seed_stride, keys_host[i], out + (int64_t)(i % out_slots) * out_stride, ldo, fresh)) return rc;
+    }
+    return SAGE_OK;
+}
+
+// Make `stream` wait for everything submitted so far (all four roles).  Also the join a stream capture needs before
+// it ends: the role streams forked from the capturing stream through the events above.
+extern "C" int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream) {
+    SAGE_REQUIRE(p, "pipe_join: NULL pipe");
+    if (p->submitted == 0) return SAGE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < 4; ++r) {
+        if (p->st[r] == st) continue;
+        bool seen = false;
+        for (int q = 0; q < r; ++q) seen |= p->st[q] == p->st[r];
+        if (seen) continue;
+        hipEvent_t e = p->ev[r][(p->submitted - 1) % (uint64_t)p->depth];
+        // the role's last record may have been skipped (same stream as its consumer): record a fresh marker
+        if (hipEventRecord(e, p->st[r]) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) {
+            sage_set_error("pipe_join: event record / wait failed");
+            return SAGE_ELAUNCH;
+        }
+    }
+    return SAGE_OK;
+}
+
+// Fork: make every role stream wait for `stream` (the start of a captured segment, or "inputs are ready").
+extern "C" int sage_pipe_fork(sage_pipe_t* p, sage_stream_t stream) {
+    SAGE_REQUIRE(p, "pipe_fork: NULL pipe");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e = p->ev_fork;
+    bool recorded = false;
+    for (int r = 0; r < 4; ++r) {
+        if (p->st[r] == st) continue;
+        bool seen = false;
+        for (int q = 0; q < r; ++q) seen |= p->st[q] == p->st[r];
+        if (seen) continue;
+        if (!recorded && hipEventRecord(e, st) != hipSuccess) { sage_set_error("pipe_fork: hipEventRecord failed"); return SAGE_ELAUNCH; }
+        recorded = true;
+        if (hipStreamWaitEvent(p->st[r], e, 0) != hipSuccess) { sage_set_error("pipe_fork: hipStreamWaitEvent failed"); return SAGE_ELAUNCH; }
+    }
+    return SAGE_OK;
+}

@@ -70,10 +70,12 @@ template <bool SAMPLE, bool FRONTIER, typename... A>
 void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
     // frontier variants use 1024-thread blocks: one global counter atomic per 1024/G nodes (256- and 512-thread
     // blocks were measured 3-5 % slower end to end)
-#ifndef SAGE_SO_THREADS
-#define SAGE_SO_THREADS 1024
-#endif
-    if constexpr (FRONTIER) launch_by_fanout_t<SAGE_SO_THREADS, SAMPLE, FRONTIER>(k, n, st, args...);
+    if constexpr (FRONTIER) {
+        const int so = sage_tunables().outer_threads;
+        if (so == 256) launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, n, st, args...);
+        else if (so == 512) launch_by_fanout_t<512, SAMPLE, FRONTIER>(k, n, st, args...);
+        else launch_by_fanout_t<1024, SAMPLE, FRONTIER>(k, n, st, args...);
+    }
 #ifndef SAGE_SI_THREADS
 #define SAGE_SI_THREADS 256
 #endif

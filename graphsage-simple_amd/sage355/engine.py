@@ -280,6 +280,115 @@ class TwoHopEngine:
 
 
 
+class RolePipeline:
+    """Consecutive 2-hop forwards software-pipelined over ROLE STREAMS (sage_pipe_*, include/sage355.h).
+
+    Stage S (outer + inner sample), G (layer-1 gather), D (layer-1 contraction) and L (layer 2) each get a HIP
+    stream; batch b+1 is gathered while batch b is contracted and batch b+2 is sampled, over `depth` workspaces.
+    Bit-identical to TwoHopEngine.forward on the same (seeds, key).  `roles` maps the four roles onto streams:
+    "SGDL" = four streams, "SGDD" = D and L share one, "SSSS" = one stream (= sage_forward2's launch order).
+    `priorities`: per distinct stream, 0 = default, -1 = high (HIP stream priority; the latency-bound roles).
+    The reference has no counterpart (model.py:240-252 is one batch at a time on the host)."""
+
+    def __init__(self, rowptr, col, table, w1, w2, k1, k2, batch, depth=4, roles="SGDL", priorities=None, **engine_kwargs):
+        import ctypes
+        if depth < 1 or depth > native.PIPE_MAX_DEPTH:
+            raise native.SageError(f"RolePipeline: depth must be in [1, {native.PIPE_MAX_DEPTH}]")
+        if len(roles) != 4:
+            raise native.SageError("RolePipeline: roles is a 4-letter map of S, G, D, L onto streams, e.g. 'SGDL' or 'SGDD'")
+        self.engines = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=batch, **engine_kwargs) for _ in range(depth)]
+        e0 = self.engines[0]
+        self.device, self.batch, self.depth, self.h2 = e0.device, int(batch), int(depth), e0.h2
+        names = []
+        for ch in roles:
+            if ch not in names:
+                names.append(ch)
+        priorities = priorities or {}
+        self._streams = {ch: torch.cuda.Stream(device=self.device, priority=int(priorities.get(ch, 0))) for ch in names}
+        self.role_streams = [self._streams[ch] for ch in roles]
+        ws = (ctypes.c_void_p * depth)(*[e.workspace.data_ptr() for e in self.engines])
+        st = (ctypes.c_void_p * 4)(*[s.cuda_stream for s in self.role_streams])
+        self._h = ctypes.c_void_p()
+        self._wkey = None
+        native.check(native.lib().sage_pipe_create(e0._model(), self.batch, depth, ws, e0.workspace.numel(), st, ctypes.byref(self._h)),
+                     "pipe_create")
+        self._wkey = self._weights_key()
+        self._keep = []
+
+    def _weights_key(self):
+        w1, w2 = self.engines[0]._weights()
+        return (w1.data_ptr(), w2.data_ptr(), w1._version, w2._version)
+
+    def _sync_weights(self):
+        key = self._weights_key()
+        if key != self._wkey:
+            w1, w2 = self.engines[0]._weights()
+            native.check(native.lib().sage_pipe_update_weights(self._h, w1.data_ptr(), w2.data_ptr()), "pipe_update_weights")
+            self._wkey = key
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                torch.cuda.synchronize()
+                native.lib().sage_pipe_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def fork(self, stream=None):
+        """Every role stream waits for `stream` (default: the current one): inputs written there are ready."""
+        s = stream or torch.cuda.current_stream()
+        native.check(native.lib().sage_pipe_fork(self._h, s.cuda_stream), "pipe_fork")
+
+    def join(self, stream=None):
+        """`stream` (default: the current one) waits for everything submitted so far."""
+        s = stream or torch.cuda.current_stream()
+        native.check(native.lib().sage_pipe_join(self._h, s.cuda_stream), "pipe_join")
+
+    def submit(self, seeds, key, out):
+        """One batch: seeds int32 [batch] device tensor, out [batch, h2] fp32 device tensor (both must stay alive
+        and unmodified until the batch has left the pipe: join() + synchronize, or an event on stream L)."""
+        if not (isinstance(seeds, torch.Tensor) and seeds.is_cuda and seeds.dtype == torch.int32 and seeds.is_contiguous()
+                and seeds.numel() == self.batch):
+            raise native.SageError("RolePipeline.submit: seeds must be a contiguous int32 device tensor of `batch` ids")
+        if out.shape != (self.batch, self.h2) or out.dtype != torch.float32 or not out.is_cuda or out.stride(1) != 1:
+            raise native.SageError("RolePipeline.submit: `out` must be a [batch, h2] fp32 device tensor with unit inner stride")
+        self._sync_weights()
+        seeds = self.engines[0]._seeds_in(seeds)
+        rc = native.lib().sage_pipe_submit(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), out.stride(0))
+        if rc != 0:
+            native.check(rc, "pipe_submit")
+
+    def submit_many(self, seeds, keys, out, segment_start=False):
+        """seeds int32 [n, batch] (device, contiguous), keys: n sampler keys, out [slots, batch, h2] with slots >= depth
+        (batch i lands in out[i % slots]) -- ONE host call enqueues all n batches."""
+        import ctypes
+        if not (isinstance(seeds, torch.Tensor) and seeds.is_cuda and seeds.dtype == torch.int32 and seeds.is_contiguous()
+                and seeds.dim() == 2 and seeds.shape[1] == self.batch):
+            raise native.SageError("RolePipeline.submit_many: seeds must be a contiguous int32 device tensor [n, batch]")
+        n = seeds.shape[0]
+        if len(keys) != n:
+            raise native.SageError("RolePipeline.submit_many: one sampler key per batch")
+        if (out.dim() != 3 or out.shape[1:] != (self.batch, self.h2) or out.dtype != torch.float32 or not out.is_cuda
+                or not out.is_contiguous() or out.shape[0] < min(self.depth, n)):
+            raise native.SageError("RolePipeline.submit_many: `out` must be a contiguous [slots >= depth, batch, h2] fp32 device tensor")
+        self._sync_weights()
+        if self.engines[0]._new_of_old is not None:
+            seeds = self.engines[0]._seeds_in(seeds).contiguous()
+            self._keep.append(seeds)
+        karr = (ctypes.c_uint64 * n)(*[int(k) & 0xFFFFFFFFFFFFFFFF for k in keys])
+        rc = native.lib().sage_pipe_submit_many(self._h, seeds.data_ptr(), self.batch, karr, n, out.data_ptr(), out.stride(1),
+                                                out.stride(0), out.shape[0], 1 if segment_start else 0)
+        if rc != 0:
+            native.check(rc, "pipe_submit_many")
+
+    def synchronize(self):
+        for s in self._streams.values():
+            s.synchronize()
+        self._keep.clear()
+
+
 class PipelinedEngine:
     """Queued forwards software-pipelined over TWO workspaces (sage_forward2_stages, include/sage355.h).
 

@@ -25,7 +25,10 @@ SYMBOLS = [
     "sage_forward2_layout", "sage_forward2_init", "sage_forward2", "sage_forward2_profiled", "sage_forward2_stages",
     "sage_forward2_gather_sample",
     "sage_linear_act_backward", "sage_gather_mean_backward",
+    "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_many",
+    "sage_pipe_join", "sage_pipe_fork",
 ]
+PIPE_MAX_DEPTH = 8
 
 
 class SageError(RuntimeError):
@@ -111,6 +114,13 @@ def lib():
     L.sage_linear_act_backward.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
                                            P, I64, P, I64, P]
     L.sage_gather_mean_backward.argtypes = [P, I64, I32, P, P, I32, I32, P, P, P, P, I64, I64, P]
+    L.sage_pipe_create.argtypes = [POINTER(Model), I32, I32, POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_void_p)]
+    L.sage_pipe_destroy.argtypes = [P]
+    L.sage_pipe_update_weights.argtypes = [P, P, P]
+    L.sage_pipe_submit.argtypes = [P, P, c_uint64, P, I64]
+    L.sage_pipe_submit_many.argtypes = [P, P, I64, POINTER(c_uint64), I32, P, I64, I64, I32, I32]
+    L.sage_pipe_join.argtypes = [P, P]
+    L.sage_pipe_fork.argtypes = [P, P]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("sage_last_error", "sage_build_arch"):

@@ -315,6 +315,39 @@ int sage_forward2_stages(const sage_model_t* m, void* workspace, size_t workspac
 int sage_forward2_gather_sample(const sage_model_t* m, void* ws_cur, void* ws_next, size_t workspace_bytes, int32_t batch,
                                 int32_t cursor_offset, sage_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Role pipeline: consecutive forwards software-pipelined over ROLE STREAMS (csrc/sage_pipe.hip).
+ * Each stage of the forward -- S: outer + inner sample, G: layer-1 gather, D: layer-1 contraction,
+ * L: layer 2 -- is enqueued on a HIP stream of its own and consecutive batches move through the
+ * stages over `depth` workspaces; hipEvents carry S(b) -> G(b) -> D(b) -> L(b) -> S(b + depth).
+ * In steady state one stage (the gather) is on the critical path instead of the sum of five.
+ * Results are bit-identical to sage_forward2 on the same (seeds, key).  The pipe owns only its
+ * hipEvents; workspaces (each laid out by sage_forward2_layout and initialised by
+ * sage_forward2_init for m->ws_batch / `batch`), streams and outputs belong to the caller.
+ * streams[4] = {S, G, D, L}; entries may coincide (the event between two roles on one stream is
+ * skipped).  All calls are host-side enqueues, capturable into a hipGraph between
+ * sage_pipe_fork(origin) and sage_pipe_join(origin).  Not thread safe per pipe.
+ * Replaces nothing in the reference (model.py:240-252 runs one batch at a time).
+ * ------------------------------------------------------------------------- */
+#define SAGE_PIPE_MAX_DEPTH 8
+typedef struct sage_pipe sage_pipe_t;
+int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t depth, void* const* workspaces,
+                     size_t workspace_bytes, const sage_stream_t* streams, sage_pipe_t** out);
+int sage_pipe_destroy(sage_pipe_t* p);
+/* The pipe keeps a COPY of *m; after an optimizer step that moved the weights elsewhere: */
+int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2);
+/* One batch: seeds int32[batch] and out float[batch, h2] must stay valid until the batch has left stream L. */
+int sage_pipe_submit(sage_pipe_t* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo);
+/* n batches from one host loop: batch i reads seeds + i*seed_stride (elements), keys_host[i] (HOST array) and
+ * writes out + (i % out_slots)*out_stride.  segment_start != 0: the first `depth` batches of this call find
+ * their workspaces free (first call on a pipe, or the first call inside a stream capture). */
+int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64_t seed_stride, const uint64_t* keys_host,
+                          int32_t n, float* out, int64_t ldo, int64_t out_stride, int32_t out_slots,
+                          int32_t segment_start);
+/* `stream` waits for everything submitted so far / every role stream waits for `stream`. */
+int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream);
+int sage_pipe_fork(sage_pipe_t* p, sage_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
