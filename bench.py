@@ -22,6 +22,11 @@ import random
 import sys
 import time
 
+# One hardware queue per role stream: ROCm's default is 4 HW queues per process, shared round-robin by all HIP streams, and two
+# role streams that land on one queue serialise (measured: role pipeline 82.6 us/forward with 4, 69.1 us with 6 or more).
+# Read by the HIP runtime when it initialises, so it must be set before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (REPO, os.path.join(REPO, "graphsage-simple_amd")):
     if p not in sys.path:
@@ -53,11 +58,23 @@ def parse():
     ap.add_argument("--mode", choices=["gcn", "concat"], default="gcn",
                     help="encoder mode: gcn = model.py:219,222 (gcn=True, no concat); concat = encoders.py:49-54")
     ap.add_argument("--unfused", action="store_true", help="two-launch layers (gather_mean + linear_act)")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every forward from the host instead of replaying a hipGraph")
-    ap.add_argument("--node-order", choices=["degree", "original"], default=os.environ.get("SAGE_NODE_ORDER", "degree"),
-                    help="degree: the generated graph's node ids are renumbered by descending degree at ingestion "
-                         "(sage355.graph.relabel_by_degree; an isomorphic graph whose most-gathered feature rows are adjacent in "
-                         "memory: gather 45 -> 43 us, forward 81 -> 77 us); original: the generator's ids")
+    ap.add_argument("--no-graph", action="store_true", help="same as --exec direct")
+    ap.add_argument("--node-order", choices=["degree", "original"], default=os.environ.get("SAGE_NODE_ORDER", "original"),
+                    help="original (default): the generator's node ids, the BASELINE workload as generated; degree: VARIANT in which "
+                         "the dataset itself is renumbered by descending degree at ingestion (sage355.graph.relabel_by_degree)")
+    ap.add_argument("--engine-layout", choices=["degree", "input"], default=os.environ.get("SAGE_ENGINE_LAYOUT", "degree"),
+                    help="device layout the engine builds from the caller's graph: degree = rows sorted by descending degree "
+                         "(TwoHopEngine(relabel='degree'): the most-gathered feature rows are neighbours in HBM; seeds keep the "
+                         "caller's ids and are translated by the outer-hop kernel inside every forward); input = the caller's order")
+    ap.add_argument("--exec", choices=["pipe", "replay", "direct"], default=os.environ.get("SAGE_EXEC", "pipe"),
+                    help="pipe: RolePipeline (stages on role streams); replay: hipGraph replay from a device batch queue, "
+                         "--streams forwards in flight; direct: host-enqueued forwards")
+    ap.add_argument("--preheat-seconds", type=float, default=float(os.environ.get("SAGE_PREHEAT", "0.5")),
+                    help="untimed forwards on throw-away batches BEFORE the W warm-up steps, until this much time has passed: a GPU that "
+                         "sat idle while the host built the inputs needs tens of ms of load to reach its sustained clocks (measured: the "
+                         "first 250 forwards of a process run 20 %% slower than the next 250); 0 = none.  Declared in config.preheat")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "4")), help="pipe: batches in flight (workspaces)")
+    ap.add_argument("--roles", default=os.environ.get("SAGE_ROLES", "SGDL"), help="pipe: roles S,G,D,L -> streams, e.g. SGDL, SGDD")
     ap.add_argument("--batches-per-replay", type=int, default=0,
                     help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "
                          "whose 20 us of GPU work per batch is less than one graph launch costs the host)")
@@ -80,6 +97,11 @@ def parse():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
     given = {a.split("=")[0].lstrip("-").replace("-", "_") for a in sys.argv[1:] if a.startswith("--")}
+    args.exec_given = "exec" in given or "SAGE_EXEC" in os.environ
+    if args.no_graph:
+        args.exec, args.exec_given = "direct", True
+    if "streams" in given and not args.exec_given:
+        args.exec, args.exec_given = "replay", True         # --streams N selects the forwards-in-flight mode it belongs to
     args.hidden1 = args.hidden
     args.truncate = 0
     for key, val in PRESETS[args.config].items():       # a preset fills what the command line left at its default
@@ -169,8 +191,8 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    from sage355 import native, ops
-    from sage355.engine import PipelinedEngine, TwoHopEngine
+    from sage355 import native
+    from sage355.engine import PipelinedEngine, RolePipeline, TwoHopEngine
     from sage355.graph import rmat_graph
     native.lib()
 
@@ -184,7 +206,7 @@ def main():
         if args.truncate:
             from sage355.graph import truncate_nodes
             g_ = truncate_nodes(g_, args.truncate)
-        if args.node_order == "degree":       # ingestion option: ids renumbered by descending degree (hub rows adjacent in HBM)
+        if args.node_order == "degree":       # VARIANT: the dataset itself renumbered by descending degree at ingestion
             from sage355.graph import relabel_by_degree
             g_ = relabel_by_degree(g_)[0]
         return g_
@@ -215,22 +237,24 @@ def main():
     seeds_dev = torch.from_numpy(seeds_host).to(dev)
     sampler_seed = [0x5A6E355 + 1000003 * rank + i for i in range(total_steps)]
 
+    # The engine keeps graph and table in a layout of its own: relabel="degree" = rows sorted by descending degree (built once
+    # in the constructor, like the dict-of-sets -> CSR conversion); seeds arrive in the GENERATOR's ids and are translated by
+    # the outer-hop kernel inside every timed forward; outputs are in the caller's seed order.
+    relabel = "degree" if (args.engine_layout == "degree" and args.config != 2 and args.node_order != "degree") else None
+    ekw = dict(concat=concat, agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel)
+    base = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, **ekw)
     nstreams = max(1, args.streams)
-    engines = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, agg_self_loop=args.self_loop, fused=not args.unfused,
-                            max_batch=b)
-               for _ in range(nstreams)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    outs = [torch.empty(b, h2, device=dev) for _ in range(nstreams)]
 
     # ---- parity gate: one batch against the fp64 oracle on the GPU's own sampled sets ----
     parity_err = None
     if not args.no_parity and rank == 0:
         from oracle import ref_sparse
-        o = engines[0].forward(seeds_dev[0], seed=sampler_seed[0]).cpu()
-        it = engines[0].intermediates()
+        o = base.forward(seeds_dev[0], seed=sampler_seed[0]).cpu()
+        it = base.intermediates()            # ids below are the engine's INTERNAL ones: index its own table copy with them
         first = it["first_frontier_row"]
         s1, nbr1, cnt1 = it["s1_nodes"].cpu().numpy(), it["nbr1"].cpu().numpy(), it["cnt1"].cpu().numpy()
-        ref = ref_sparse.two_hop_forward(table.cpu(), w1.cpu(), w2.cpu(), seeds_host[0], it["nbr2"].cpu().numpy(),
+        seeds_int = seeds_host[0] if base._new_of_old is None else base._new_of_old[torch.from_numpy(seeds_host[0]).long().to(dev)].cpu().numpy()
+        ref = ref_sparse.two_hop_forward(base.table.cpu(), w1.cpu(), w2.cpu(), seeds_int, it["nbr2"].cpu().numpy(),
                                          it["cnt2"].cpu().numpy(), s1[first:], nbr1[first:], cnt1[first:], gcn=not concat,
                                          agg_gcn=args.self_loop,
                                          seed_nbr1=nbr1[:first] if concat else None, seed_cnt1=cnt1[:first] if concat else None)
@@ -239,46 +263,66 @@ def main():
         if not parity_err <= 1e-5:
             raise SystemExit(f"parity gate failed: max |gpu-oracle|/rowmax = {parity_err:.3e}")
 
-    # hipGraph replay: stream s owns steps s, s+S, s+2S, ... as a device-side queue of batch descriptors, so one
-    # graph launch per step is ALL the host does inside the timed region
-    use_graph = not args.no_graph
-    # pipelined replay embeds two batches per graph launch: the step counts must split into whole pairs per stream
-    pipelined = bool(args.pipeline) and use_graph and args.warmup % (2 * nstreams) == 0 and args.steps % (2 * nstreams) == 0
-    pipes = []
+    # ---- execution modes of the timed region ----
+    #  pipe   (default): RolePipeline -- stages S / G / D / L on role streams, `depth` batches in flight, one host call per batch
+    #  replay          : hipGraph replay from a device batch queue, `streams` independent forwards in flight (round 1's mode)
+    #  direct          : host-enqueued sage_forward2 calls
+    exec_mode = args.exec
+    if args.pipeline:
+        exec_mode = "replay"
     bpr = args.batches_per_replay if args.batches_per_replay > 0 else (10 if args.config == 2 else 1)
-    if pipelined:
-        pair = np.arange(total_steps) // 2
-        for s in range(nstreams):
-            mine = np.nonzero(pair % nstreams == s)[0]
-            pe = PipelinedEngine(rowptr, col, table, w1, w2, k1, k2, concat=concat, agg_self_loop=args.self_loop,
-                                 fused=not args.unfused, max_batch=b, mode="fused" if args.pipeline == 2 else "branches")
-            pe.set_queue(seeds_dev[torch.from_numpy(mine).to(dev)].contiguous(), [sampler_seed[i] for i in mine])
-            with torch.cuda.stream(streams[s]):
-                pe.capture()
-            pipes.append(pe)
+    if args.config == 2 and args.exec == "pipe" and not args.exec_given:
+        exec_mode = "replay"        # 256-seed batches: 20 us of GPU work per batch, less than the host's enqueue per batch
+    pipe = None
+    engines, streams, outs, pipes = [], [], [], []
+    pipelined = False
+    if exec_mode == "pipe":
+        pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, **ekw)
+        pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
         torch.cuda.synchronize()
-    elif use_graph:
-        if bpr > 1 and (args.warmup % (bpr * nstreams) or args.steps % (bpr * nstreams)):
-            bpr = 1                                   # the step counts must split into whole replays per stream
-        group = np.arange(total_steps) // bpr
-        for s in range(nstreams):
-            mine = torch.from_numpy(np.nonzero(group % nstreams == s)[0]).to(dev)
-            engines[s].set_queue(seeds_dev[mine].contiguous(), [sampler_seed[int(i)] for i in mine.cpu()])
-            with torch.cuda.stream(streams[s]):
-                if bpr == 1:
-                    engines[s].capture(out=outs[s])
-                else:
-                    engines[s].capture(batches=bpr)
-        torch.cuda.synchronize()
+    else:
+        engines = [base] + [base.sibling() for _ in range(nstreams - 1)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        outs = [torch.empty(b, h2, device=dev) for _ in range(nstreams)]
+        use_graph = exec_mode == "replay"
+        pipelined = bool(args.pipeline) and use_graph and args.warmup % (2 * nstreams) == 0 and args.steps % (2 * nstreams) == 0
+        if pipelined:
+            pair = np.arange(total_steps) // 2
+            for s in range(nstreams):
+                mine = np.nonzero(pair % nstreams == s)[0]
+                pe = PipelinedEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, mode="fused" if args.pipeline == 2 else "branches", **ekw)
+                pe.set_queue(seeds_dev[torch.from_numpy(mine).to(dev)].contiguous(), [sampler_seed[i] for i in mine])
+                with torch.cuda.stream(streams[s]):
+                    pe.capture()
+                pipes.append(pe)
+            torch.cuda.synchronize()
+        elif use_graph:
+            if bpr > 1 and (args.warmup % (bpr * nstreams) or args.steps % (bpr * nstreams)):
+                bpr = 1                                   # the step counts must split into whole replays per stream
+            group = np.arange(total_steps) // bpr
+            for s in range(nstreams):
+                mine = torch.from_numpy(np.nonzero(group % nstreams == s)[0]).to(dev)
+                engines[s].set_queue(seeds_dev[mine].contiguous(), [sampler_seed[int(i)] for i in mine.cpu()])
+                with torch.cuda.stream(streams[s]):
+                    if bpr == 1:
+                        engines[s].capture(out=outs[s])
+                    else:
+                        engines[s].capture(batches=bpr)
+            torch.cuda.synchronize()
 
-    def run(step_range, profiled_events=None):
-        if pipelined and profiled_events is None:
+    def run(step_range):
+        if pipe is not None:
+            lo, hi = step_range.start, step_range.stop
+            if hi > lo:
+                pipe.submit_many(seeds_dev[lo:hi], sampler_seed[lo:hi], pipe_out)       # ONE host call enqueues all of them
+            return
+        if pipelined:
             for j in range(step_range.start // 2, step_range.stop // 2):      # one replay = steps 2j, 2j+1
                 s = j % nstreams
                 with torch.cuda.stream(streams[s]):
                     pipes[s].replay()
             return
-        if use_graph and bpr > 1 and profiled_events is None:
+        if exec_mode == "replay" and bpr > 1:
             for j in range(step_range.start // bpr, step_range.stop // bpr):  # one replay = steps j*bpr .. j*bpr + bpr - 1
                 s = j % nstreams
                 with torch.cuda.stream(streams[s]):
@@ -287,9 +331,7 @@ def main():
         for i in step_range:
             s = i % nstreams
             with torch.cuda.stream(streams[s]):
-                if profiled_events is not None:
-                    engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s], stage_events=profiled_events[i])
-                elif use_graph:
+                if exec_mode == "replay":
                     engines[s].replay()
                 else:
                     engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s])
@@ -300,6 +342,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- preheat (untimed, throw-away batches, same execution mode), then W warm-up steps, then the timed region ----
+    preheat_forwards = 0
+    if args.preheat_seconds > 0:
+        ph_rs = np.random.default_rng(777 + rank)
+        ph_n = 32
+        ph_seeds = torch.from_numpy(np.stack([ph_rs.choice(candidates, b, replace=False) for _ in range(ph_n)]).astype(np.int32)).to(dev)
+        ph_keys = [0xBEEF + i for i in range(ph_n)]
+        ph_eng = base if pipe is None else None
+        t_ph = time.perf_counter()
+        while time.perf_counter() - t_ph < args.preheat_seconds:
+            if pipe is not None:
+                pipe.submit_many(ph_seeds, ph_keys, pipe_out)
+            else:
+                for i in range(ph_n):
+                    ph_eng.forward(ph_seeds[i], seed=ph_keys[i])
+            torch.cuda.synchronize()
+            preheat_forwards += ph_n
+        if pipe is None and exec_mode == "replay":
+            for e_ in engines:                    # the preheat used engine 0 directly: queue cursors are untouched, nothing to rewind
+                pass
     # ---- warm-up, then the timed region: exactly K steps between two barrier+synchronize fences ----
     run(range(args.warmup))
     fence()
@@ -314,19 +376,40 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * b * args.steps / elapsed
 
-    # ---- dominant kernel (layer 1) duration: the same K steps again, same streams in flight, host-enqueued with HIP
-    #      events on the kernel's own stream; the data-determined set sizes of every batch are counted in the same
-    #      pass by torch reductions enqueued behind each forward (no host sync inside the pass) ----
     workload = (f"BASELINE configs[{args.config - 1}]: "
                 + ("Pubmed topology (19717 nodes)" if args.config == 2 else
                    f"R-MAT 2^{args.scale} / {args.edges} edges" + (f" truncated to {n} nodes" if args.truncate else f" ({n} nodes)"))
                 + (", node ids renumbered by degree at ingestion" if (args.node_order == "degree" and args.config != 2) else "")
                 + f", {graph.nnz} directed nnz, {d0}-dim fp32 features, 2-layer GraphSAGE-mean {args.mode} encoder"
-                + (" + self-loop (GCN-variant) aggregator" if args.self_loop else "")
+                + (" + self-loop (GCN-variant) aggregator [intended semantics of aggregators.py:50-51; the reference line raises TypeError, so this variant is parity-unpinned]" if args.self_loop else "")
                 + f" H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU")
+
+    # ---- dominant kernel (layer-1 gather) duration, measured live with HIP events on the kernel's own stream:
+    #      (a) IN SITU: the same K steps again in the same execution mode (the pipeline running, events around the gather on
+    #          stream G) -- what the timed region's kernel launches took, overlap stretch included;
+    #      (b) ALONE: host-enqueued forwards, one batch in flight -- the kernel's own speed.
+    #      Both are RAW event intervals (an upper bound of the kernel's duration: they include the event packets).
+    #      The data-determined set sizes of every batch are counted by torch reductions after pass (b). ----
     roofline = None
     if rank == 0:
         he = HipEvents()
+        split = bool(base.layout.layer1_split)      # layer 1 ran as column-sliced gather + dense contraction
+        insitu_ms = None
+        if pipe is not None and split:
+            pairs = []
+            for i in range(args.warmup, total_steps):
+                arr = (ctypes.c_void_p * 2)(he.create(), he.create())
+                pairs.append(arr)
+            torch.cuda.synchronize()
+            for i in range(args.warmup):
+                pipe.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
+            for j, i in enumerate(range(args.warmup, total_steps)):
+                pipe.submit_profiled(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]], pairs[j])
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            insitu_ms = sum(he.elapsed_ms(a_[0], a_[1]) for a_ in pairs) / len(pairs)
+            for a_ in pairs:
+                he.destroy(a_[0]); he.destroy(a_[1])
         evs = {}
         for i in range(args.warmup, total_steps):
             arr = (ctypes.c_void_p * 10)()
@@ -334,60 +417,57 @@ def main():
                 arr[j] = he.create()
             evs[i] = arr
         stats = torch.zeros(total_steps, 4, dtype=torch.int64, device=dev)       # E2, |S1|, E1, |R1| per step
-        flags = [torch.zeros(n + 1, dtype=torch.int32, device=dev) for _ in range(nstreams)]
+        flag = torch.zeros(n + 1, dtype=torch.int32, device=dev)
         col_idx = torch.arange(k1, device=dev)[None, :]
+        e = base
+        L = e.layout
+        first = b if concat else 0
         torch.cuda.synchronize()
         for i in range(args.warmup, total_steps):
-            s = i % nstreams
-            e = engines[s]
-            with torch.cuda.stream(streams[s]):
-                e.forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s], stage_events=evs[i])
-                L = e.layout
-                first = b if concat else 0
-                n_s1 = e._view(L.counters, 16, torch.int32)[8].long() + first          # device scalar
-                cnt2 = e._view(L.cnt2, b, torch.int32)
-                cnt1 = e._view(L.cnt1, L.max_s1, torch.int32)
-                nbr1 = e._view(L.nbr1, L.max_s1 * k1, torch.int32).view(L.max_s1, k1)
-                live = torch.arange(L.max_s1, device=dev) < n_s1
-                valid = live[:, None] & (col_idx < cnt1[:, None])
-                ids = torch.where(valid, nbr1, n).long()
-                f = flags[s]
-                f.zero_()
-                f.scatter_(0, ids.reshape(-1), 1)
-                if concat or args.self_loop:
-                    s1 = e._view(L.s1_nodes, L.max_s1, torch.int32)
-                    f.scatter_(0, torch.where(live, s1, n).long(), 1)
-                stats[i, 0] = cnt2.sum()
-                stats[i, 1] = n_s1
-                stats[i, 2] = torch.where(live, cnt1, 0).sum()
-                stats[i, 3] = f[:n].sum()
+            e.forward(seeds_dev[i], seed=sampler_seed[i], stage_events=evs[i])
+            n_s1 = e._view(L.counters, 16, torch.int32)[8].long() + first          # device scalar
+            cnt2 = e._view(L.cnt2, b, torch.int32)
+            cnt1 = e._view(L.cnt1, L.max_s1, torch.int32)
+            nbr1 = e._view(L.nbr1, L.max_s1 * k1, torch.int32).view(L.max_s1, k1)
+            live = torch.arange(L.max_s1, device=dev) < n_s1
+            valid = live[:, None] & (col_idx < cnt1[:, None])
+            ids = torch.where(valid, nbr1, n).long()
+            flag.zero_()
+            flag.scatter_(0, ids.reshape(-1), 1)
+            if concat or args.self_loop:
+                s1 = e._view(L.s1_nodes, L.max_s1, torch.int32)
+                flag.scatter_(0, torch.where(live, s1, n).long(), 1)
+            stats[i, 0] = cnt2.sum()
+            stats[i, 1] = n_s1
+            stats[i, 2] = torch.where(live, cnt1, 0).sum()
+            stats[i, 3] = flag[:n].sum()
         torch.cuda.synchronize()
         stage = np.zeros(5)
         gap = 0.0
-        split = bool(engines[0].layout.layer1_split)      # layer 1 ran as column-sliced gather + dense contraction
         for i, arr in evs.items():
             for sidx in range(5):
                 stage[sidx] += he.elapsed_ms(arr[2 * sidx], arr[2 * sidx + 1])
-            # events 1->2 and 7->8 are recorded back to back with NO kernel between them: what an event pair costs
-            # by itself on this stream (the record packets), measured live in the same pass
-            gap += 0.5 * (he.elapsed_ms(arr[1], arr[2]) + he.elapsed_ms(arr[7], arr[8]))
+            gap += 0.5 * (he.elapsed_ms(arr[1], arr[2]) + he.elapsed_ms(arr[7], arr[8]))   # an event pair with nothing between
             for j in range(10):
                 he.destroy(arr[j])
         stage /= args.steps
         gap /= args.steps
         if not split:
             stage[2] = 0.0
-        layer1_raw_ms = float(stage[2]) if split else float(stage[3])
-        # kernel duration = event interval minus the empty-pair interval (rocprofv3's kernel time is what this must agree with)
-        layer1_ms = max(layer1_raw_ms - gap, 1e-6)
+        alone_ms = float(stage[2]) if split else float(stage[3])
+        kernel_ms = insitu_ms if insitu_ms is not None else alone_ms
         st = stats[args.warmup:].cpu().numpy().astype(np.float64)
-        tot = l1 = 0.0
+        tot = l1 = own = 0.0
         for e2, n_s1, e1, n_r1 in st:
             t_, l_, g_ = algorithmic_bytes(d0, h1, h2, mult * d0, mult * h1, b, n_s1, e1, e2, n_r1)
             tot += t_
-            l1 += g_ if split else l_
+            # SURVEY 8(d) bytes of the work this kernel does: unique raw rows in + sampled ids in (+ counts); the [|S1|, D0]
+            # means it writes for the contraction are a round trip the split design itself adds -- reported separately
+            l1 += (g_ - 4 * d0 * n_s1) if split else l_
+            own += g_ if split else l_
         tot /= args.steps
         l1 /= args.steps
+        own /= args.steps
         sizes = st.mean(0)
         per_edge = 4 * d0 * sizes[2] + 4 * h1 * sizes[0]
         traffic = None
@@ -395,26 +475,42 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))          # PMC passes are separate runs (profiles/collect.sh): only valid
-                if tj.get("workload", workload) == workload and split:     # for the workload they were collected on
+                if tj.get("workload", workload) == workload and tj.get("engine_layout") == (relabel or "input") and split:
                     traffic = tj.get("layer1_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        achieved = l1 / (layer1_ms * 1e-3) / 1e9
+        achieved = l1 / (kernel_ms * 1e-3) / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "gather_mean_sliced_kernel (layer 1 gather-mean)" if split
+            "bound": "hbm", "kernel": "gather_mean_rows_kernel / gather_mean_sliced* (layer-1 gather-mean)" if split
             else "layer_fused_kernel (layer 1: gather-mean + W1 contraction)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
-            "traffic": traffic, "bytes_per_launch": round(l1), "kernel_ms": round(layer1_ms, 5),
-            "kernel_ms_event_interval": round(layer1_raw_ms, 5), "empty_event_pair_ms": round(gap, 5),
-            "stage_ms": {"sample_outer": round(float(stage[0]), 5), "sample_inner": round(float(stage[1]), 5),
-                         "layer1_gather": round(float(stage[2]), 5), "layer1_contract": round(float(stage[3]), 5),
-                         "layer2": round(float(stage[4]), 5)},
+            "traffic": traffic, "bytes_per_launch": round(l1),
+            "bytes_note": "SURVEY 8(d) compulsory bytes of the kernel's work (unique raw rows + sampled ids + counts); its own write of "
+                          "the [|S1|, D0] means (a round trip the split layer adds) is excluded here and included in bytes_per_launch_own",
+            "bytes_per_launch_own": round(own),
+            "kernel_ms": round(kernel_ms, 5),
+            "kernel_ms_is": ("raw HIP-event interval around the launch on its own stream, measured in the running role pipeline "
+                             "(overlap with the other stages' kernels included)" if insitu_ms is not None else
+                             "raw HIP-event interval around the launch on its own stream, one batch in flight"),
+            "kernel_ms_alone": round(alone_ms, 5), "frac_alone": round(l1 / (alone_ms * 1e-3) / HBM_PEAK, 4),
+            "empty_event_pair_ms": round(gap, 5),
+            "stage_ms_alone": {"sample_outer": round(float(stage[0]), 5), "sample_inner": round(float(stage[1]), 5),
+                               "layer1_gather": round(float(stage[2]), 5), "layer1_contract": round(float(stage[3]), 5),
+                               "layer2": round(float(stage[4]), 5)},
             "forward_bytes": round(tot), "forward_GBps": round(tot / (ms_per_step * 1e-3) / 1e9, 1),
             "forward_frac": round(tot / (ms_per_step * 1e-3) / HBM_PEAK, 4),
             "per_edge_gather_bytes": round(float(per_edge)),
             "mean_sizes": {"E2": round(float(sizes[0]), 1), "S1": round(float(sizes[1]), 1), "E1": round(float(sizes[2]), 1),
                            "R1": round(float(sizes[3]), 1)},
         }
+        mfile = os.path.join(REPO, "profiles", "mfma.json")
+        if os.path.exists(mfile):
+            try:
+                mj = json.load(open(mfile))
+                if mj.get("workload", workload) == workload:
+                    roofline["mfma"] = mj.get("kernels")
+            except Exception:
+                pass
 
     # ---- CPU side by side: the reference-faithful restatement on this box's host cores ----
     cpu_baseline = None
@@ -422,14 +518,26 @@ def main():
         cpu_baseline = cpu_port_baseline(graph, table.cpu(), w1.cpu(), w2.cpu(), candidates, k1, k2, concat, args.cpu_seconds)
 
     if rank == 0:
+        if pipe is not None:
+            execution = f"role pipeline {args.roles} (stages S/G/D/L on HIP streams, hipEvent hand-offs), {args.depth} batches in flight"
+        elif exec_mode == "replay":
+            execution = f"hipGraph replay from a device batch queue, {nstreams} forwards in flight"
+        else:
+            execution = f"host-enqueued sage_forward2, {nstreams} forwards in flight"
         line = {
             "metric": "node-embeddings/sec (2-hop forward)", "value": round(value, 1), "unit": "embeddings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
-                       "streams_in_flight": nstreams, "fused_layers": not args.unfused, "hip_graph_replay": use_graph,
-                       "node_order": args.node_order if args.config != 2 else "original", "pipelined_sampling": pipelined, "batches_per_replay": 2 if pipelined else (bpr if use_graph else 1),
+                       "execution": execution, "fused_layers": not args.unfused,
+                       "preheat": f"{preheat_forwards} untimed forwards on throw-away batches before the {args.warmup} warm-up steps (GPU clock ramp)",
+                       "node_order": args.node_order if args.config != 2 else "original",
+                       "engine_layout": (relabel or "input") + (" (internal: rows by descending degree; seeds arrive in the generator's ids and are "
+                                                                "translated inside every timed forward)" if relabel else ""),
+                       "contraction": "bf16x3-split MFMA (fp32-accurate: x.w from the three bf16 terms of x and of w; weight planes prepared "
+                                      "once per weight update by sage_prepare_weights)",
+                       "pipelined_sampling": pipelined, "batches_per_replay": 2 if pipelined else (bpr if exec_mode == "replay" else 1),
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
             "parity_max_err_vs_fp64_oracle": parity_err,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -15,6 +15,7 @@ ap.add_argument("--order", default="original")
 ap.add_argument("--configs", nargs="*", default=["4:SGDL:", "4:SGDL:S-1,D-1,L-1", "3:SGDD:", "4:SGDD:S-1,D-1", "2:SSSS:", "6:SGDL:S-1,D-1,L-1"])
 ap.add_argument("--baseline", type=int, default=1)
 ap.add_argument("--tag", default="")
+ap.add_argument("--bstreams", type=int, nargs="*", default=[1, 2])
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = rmat_graph(20, 16_000_000, seed=0, cache_dir="/tmp/sage_cache")
@@ -40,7 +41,7 @@ def timed(fn_warm, fn_run):
     return (time.perf_counter() - t0) / args.steps * 1e6
 
 if args.baseline:
-    for ns in (1, 2):
+    for ns in args.bstreams:
         engs = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b) for _ in range(ns)]
         sts = [torch.cuda.Stream() for _ in range(ns)]
         outs = [torch.empty(b, h2, device=dev) for _ in range(ns)]

@@ -29,11 +29,18 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
 const sage_tunables_t& sage_tunables() {
     static const sage_tunables_t t = [] {
         sage_tunables_t x;
-        x.gather_blocks_per_cu = env_int("SAGE_G_PER_CU", 8, 1, 8);
-        x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU * 3 / 4, 32, 512);
+        x.gather_blocks_per_cu = env_int("SAGE_G_PER_CU", 6, 1, 8);
+        { const int sl = env_int("SAGE_G_SLICE_LANES", 0, 0, 32); x.gather_slice_lanes = (sl == 8 || sl == 16 || sl == 32) ? sl : 0; }
+        x.gather_rows_in_flight = env_int("SAGE_G_ROWS", 1, 1, 4);
+        x.gather_trip = env_int("SAGE_G_TRIP", 16, 8, 16) >= 16 ? 16 : 8;
+        x.gather_variant = env_int("SAGE_G_VARIANT", 1, 0, 2);
+        x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU, 32, 512);
+        x.dense_variant = env_int("SAGE_DENSE_VARIANT", 0, 0, 1);
+        x.dense_prefetch = env_int("SAGE_DENSE_PREFETCH", 1, 0, 1);
         const int so = env_int("SAGE_SO_THREADS", 1024, 256, 1024);
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);
+        x.tile16_waves = env_int("SAGE_T16_WAVES", 16, 8, 16) >= 16 ? 16 : 8;
         return x;
     }();
     return t;

@@ -24,6 +24,7 @@ struct DenseArgs {
     const float* W; int64_t ldw; int out_dim; int act;
     float* out; int64_t ldo;
     sage_finish_t fin;
+    const uint4* wsplit;      // nullable: W already split into bf16 planes in register order (sage_prepare_weights)
 };
 
 // Concat encoder (K = 2*dim): with KP <= 128 a wave keeps BOTH chunks of its W slice in registers; at KP = 256 the
@@ -193,6 +194,15 @@ int launch(const DenseArgs& a, hipStream_t st) {
 #ifndef SAGE_MP_TG
 #define SAGE_MP_TG 1
 #endif
+#ifdef SAGE_DENSE_STAMPS     // diagnostic build (experiments/): where a persistent block's time goes; never in the product library
+__device__ unsigned long long g_dense_stamps[512 * 40];
+extern "C" int sage_debug_dense_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dense_stamps), sizeof(g_dense_stamps)) == hipSuccess ? 0 : -1;
+}
+#define STAMP(i) do { if (threadIdx.x == 0 && (i) < 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_dense_stamps[blockIdx.x * 40 + (i)] = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x8 = __attribute__((ext_vector_type(8))) float;
@@ -224,8 +234,9 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
     static_assert(RPW % RPP == 0 && KH % 16 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int PLD = 128 + 4;                         // floats per row of a partial-sum plane (+16 B: conflict-free b128 reads)
     __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);                                   // [2][3][M][LDB]
-    float* red = reinterpret_cast<float*>(lds_raw + (size_t)2 * 3 * PL * sizeof(__bf16));  // [4][16][64]
+    float* part = reinterpret_cast<float*>(lds_raw + (size_t)2 * 3 * PL * sizeof(__bf16));  // [2 K halves][M][PLD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nn = a.n;
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const int lg = lane & (LG - 1), sg = lane / LG;
         const int c0 = lg * 4;
         const int stride = (int)gridDim.x;
+        const bool vec_store = (a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
         const int ppc = MP ? (a.dim + KP - 1) / KP : 1;          // passes per K chunk
         const int npass = (CHUNKS / PCH) * ppc;
 
@@ -280,6 +292,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 }
         };
 
+        STAMP(0);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
         // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = pass*KPASS + kgroup*KH + 16 st + 8 h
@@ -290,6 +303,23 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
         bf16x8 bw[STEPS][3];
         auto load_w = [&](int pass) {
+            if constexpr (!MULTI) {
+                if (a.wsplit) {
+                    // planes prepared by sage_prepare_weights: [wave][step][plane][lane] x 16 B, so every load is one
+                    // fully coalesced 1-KiB wave-instruction and nothing is split here (the strided fp32 loads + 16 split3
+                    // per lane below took 8000 cycles per wave and ~15000 until the block's slowest wave had its slice:
+                    // a third of the kernel, in-kernel s_memtime stamps)
+                    const uint4* wp = a.wsplit + ((size_t)wave * STEPS * 3) * 64 + lane;
+#pragma unroll
+                    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const uint4 v = wp[(st * 3 + pl) * 64];
+                            bw[st][pl] = __builtin_bit_cast(bf16x8, v);
+                        }
+                    return;
+                }
+            }
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 const int kk = (pass % ppc) * KPASS + kgroup * KH + 16 * st + 8 * h;       // column inside the pass's first chunk ...
@@ -306,6 +336,9 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
             }
         };
         if (!MULTI) load_w(0);
+        STAMP(1);
+        int stamp_i = 2;
+        (void)stamp_i;
 
         int b = 0;
         for (int t0 = (int)blockIdx.x; t0 < ntiles; t0 += TG * stride) {
@@ -329,6 +362,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     __bf16* buf = lds + b * 3 * PL;
                     stage_tile(buf);
                     __syncthreads();
+                    STAMP(stamp_i); ++stamp_i;
                     // the next work item's rows are in flight during the MFMA loop below
                     if (t + 1 < TG && tile + stride < ntiles) request_tile(tile + stride, pass);
                     else if (pass + 1 < npass) request_tile(t0, pass + 1);
@@ -348,6 +382,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], acc[t], 0, 0, 0);
                         }
                     }
+                    STAMP(stamp_i); ++stamp_i;
                     b ^= 1;
                 }
             
@@ -358,44 +393,203 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 #pragma unroll
                 for (int pass = 0; pass < CHUNKS / PCH; ++pass) do_pass(pass);
             }
-            float* myred = red + (wave & 3) * 16 * 64;        // K half 1 -> LDS -> K half 0
+            // Epilogue: both K halves put their 32 x 32 partial sums into LDS as [row][column] planes, then ALL eight waves
+            // add the halves, apply the activation and store whole rows: 64 lanes x 16 B = two 512-B rows per instruction, two
+            // instructions per wave and tile.  (Before: K half 1 -> LDS -> K half 0, whose four waves then issued 16 scalar
+            // 4-byte stores per lane: 5300 of a tile's 9000 cycles, in-kernel stamps.)  Sum order unchanged: half 0 + half 1.
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
                 const int tile = t0 + t * stride;
                 if (tile >= ntiles) continue;
                 if (TG > 1 && t > 0) __syncthreads();         // the previous tile's partial sums have been read
-                if (kgroup == 1) {
+                if (mfma_wave) {
+                    float* mine = part + (size_t)kgroup * M * PLD + n0 + i32;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) myred[e * 64 + lane] = acc[t][e];
+                    for (int reg = 0; reg < 16; ++reg) mine[((reg & 3) + 8 * (reg >> 2) + 4 * h) * PLD] = acc[t][reg];
                 }
                 __syncthreads();
-                if (kgroup == 0) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[t][e] += myred[e * 64 + lane];
-                    const int col = n0 + i32;
-                    if (mfma_wave && col < a.out_dim) {
+                for (int it = 0; it < M / (WAVES * 2); ++it) {
+                    const int row = wave * (M / WAVES) + 2 * it + (lane >> 5);
+                    const int col = (lane & 31) * 4;
+                    const int g = tile * M + row;
+                    if (g < nn && col < a.out_dim) {
+                        const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + row * PLD + col);
+                        const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (M + row) * PLD + col);
+                        f32x4 v;
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-#ifndef SAGE_NO_NT_STORES   // streaming stores: the next kernel reads these rows from other XCDs anyway, and dirty lines left in L2 are
-                            // written back at the kernel boundary, on the critical path (gather 49.4 -> 48.3 us, contraction 22.2 -> 21.3)
-                            if (g < nn) __builtin_nontemporal_store(sage_activate(acc[t][reg], a.act), &a.out[(int64_t)g * a.ldo + col]);
-#else
-                            if (g < nn) a.out[(int64_t)g * a.ldo + col] = sage_activate(acc[t][reg], a.act);
-#endif
+                        for (int e = 0; e < 4; ++e) v[e] = sage_activate(p0[e] + p1[e], a.act);
+                        float* dst = a.out + (int64_t)g * a.ldo + col;
+                        if (col + 3 < a.out_dim && vec_store) {
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (col + e < a.out_dim) __builtin_nontemporal_store(v[e], dst + e);
                         }
                     }
                 }
+                STAMP(stamp_i); ++stamp_i;
             }
+        }
+        STAMP(39);
+    }
+    sage_finish_block(a.fin, (int)gridDim.x);
+}
+
+
+// ---- the split-bf16 contraction in a SMALL footprint: 256-thread blocks that own 64 of the output columns ------------
+// dense_bf16x3_kernel above holds 352 of a SIMD's 512 VGPRs and 117 KB of LDS per block: it cannot share a CU with the
+// layer-1 gather of another batch (240-256 VGPRs per SIMD), so in the role pipeline (sage_pipe.hip) its blocks waited for
+// whole gathers to drain (rocprofv3 timeline: 24 us alone, 52-60 us beside a gather).  Here a block is 4 waves -- ONE per
+// SIMD -- that own output columns [64 c, 64 c + 64) (c = blockIdx & 1) as 2 column groups x 2 K halves; a wave's W slice
+// (32 columns x K/2, three bf16 planes) is the same 96 VGPRs, but a SIMD carries one such wave instead of two, the A tile
+// is single-buffered (48 KB) and each 32-row tile is staged by two blocks (once per column half; the second read is an
+// L2 / Infinity-Cache hit).  Same arithmetic, same summation order per output element as dense_bf16x3_kernel (K half 0
+// then + K half 1), so results are bit-identical to it.  Non-concat layers with dim <= 256 only.
+template <int KP, bool PREFETCH>
+__global__ __launch_bounds__(256) void dense_bf16x3_c64_kernel(const DenseArgs a) {
+    constexpr int M = 32, WAVES = 4;
+    constexpr int KH = KP / 2, STEPS = KH / 16;
+    constexpr int LDB = KP + 8;                          // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
+    constexpr int PL = M * LDB;                          // elements per plane
+    constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
+    static_assert(RPW % RPP == 0 && KH % 16 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);                                        // [3][M][LDB]
+    float* red = reinterpret_cast<float*>(lds_raw + (size_t)3 * PL * sizeof(__bf16));      // [2][16][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nn = a.n;
+    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
+    const int ntiles = (nn + M - 1) / M;
+    const int chalf = (int)(blockIdx.x & 1), stride = (int)(gridDim.x >> 1);
+    const int first = (int)(blockIdx.x >> 1);
+    if (first < ntiles) {
+        const bool nan_rule = (a.cnt && a.any_nonempty) ? (*a.any_nonempty != 0) : false;
+        const int i32 = lane & 31, h = lane >> 5;
+        const int cgrp = wave & 1, kgroup = wave >> 1;
+        const int n0 = chalf * 64 + cgrp * 32;
+        const bool mfma_wave = n0 < a.out_dim;
+        const int lg = lane & (LG - 1), sg = lane / LG;
+        const int c0 = lg * 4;
+
+        f32x4 xr[PASSES];
+        auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int g = tile * M + wave * RPW + p * RPP + sg;
+                xr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g < nn && c0 < a.dim) {
+                    xr[p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
+                    if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[p] = f32x4{q, q, q, q}; }
+                }
+            }
+        };
+        auto stage_tile = [&]() {                            // VGPRs -> split -> three bf16 LDS planes
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int r = wave * RPW + p * RPP + sg;
+                bf16x4 hi, mid, lo;
+                split3(xr[p], hi, mid, lo);
+                __bf16* dst = lds + r * LDB + c0;
+                *reinterpret_cast<bf16x4*>(dst) = hi;
+                *reinterpret_cast<bf16x4*>(dst + PL) = mid;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PL) = lo;
+            }
+        };
+        request_tile(first);                                 // travels while W is fetched and split
+
+        const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
+        const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
+        bf16x8 bw[STEPS][3];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int kc = kgroup * KH + 16 * st + 8 * h;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + kc);
+            if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + kc + 4);
+            bf16x4 h0, m0, l0, h1, m1, l1;
+            split3(v0, h0, m0, l0);
+            split3(v1, h1, m1, l1);
+            bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+
+        for (int tile = first; tile < ntiles; tile += stride) {
+            if (!PREFETCH && tile != first) request_tile(tile);
+            stage_tile();
+            __syncthreads();
+            if (PREFETCH && tile + stride < ntiles) request_tile(tile + stride);      // in flight during the MFMA loop
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            if (mfma_wave) {
+                const __bf16* abase = lds + i32 * LDB + kgroup * KH + 8 * h;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(abase + 16 * st);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(abase + PL + 16 * st);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(abase + 2 * PL + 16 * st);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw[st][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], acc, 0, 0, 0);
+                }
+            }
+            float* myred = red + cgrp * 16 * 64;              // K half 1 -> LDS -> K half 0
+            if (kgroup == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) myred[e * 64 + lane] = acc[e];
+            }
+            __syncthreads();                                  // also: every wave has read the A tile
+            if (kgroup == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] += myred[e * 64 + lane];
+                const int col = n0 + i32;
+                if (mfma_wave && col < a.out_dim) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        if (g < nn) __builtin_nontemporal_store(sage_activate(acc[reg], a.act), &a.out[(int64_t)g * a.ldo + col]);
+                    }
+                }
+            }
+            // the next stage_tile overwrites the A planes (all waves are past the barrier above, so they have read them)
+            // and the next K-half hand-over overwrites `red`, which K half 0 has read before ITS next barrier
         }
     }
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
+template <int KP>
+int launch_bf16x3_c64(const DenseArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * 32 * (KP + 8) * 2 + (size_t)2 * 16 * 64 * sizeof(float);
+    static bool configured = false;
+    const bool prefetch = sage_tunables().dense_prefetch != 0;
+    if (!configured) {
+        if (lds > 64 * 1024 && (hipFuncSetAttribute((const void*)dense_bf16x3_c64_kernel<KP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                                hipFuncSetAttribute((const void*)dense_bf16x3_c64_kernel<KP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)) {
+            sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
+            return SAGE_ELAUNCH;
+        }
+        configured = true;
+    }
+    // two blocks (column halves) per tile; an even grid
+    const int grid = 2 * min(sage_cdiv(a.n, 32), max(sage_tunables().dense_blocks, 2) / 2);
+    if (prefetch) hipLaunchKernelGGL((dense_bf16x3_c64_kernel<KP, true>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((dense_bf16x3_c64_kernel<KP, false>), dim3(grid), dim3(256), lds, st, a);
+    SAGE_CHECK_LAUNCH("dense_bf16x3_c64_kernel");
+    return SAGE_OK;
+}
+
 template <int KP, bool CONCAT, bool MP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
-    constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)4 * 16 * 64 * sizeof(float);
+    constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -415,7 +609,69 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     return SAGE_OK;
 }
 
+// W [out_dim, dim] fp32 -> three bf16 planes in the register order of dense_bf16x3_kernel<KP, false, false>:
+// prepared[((wave * STEPS + st) * 3 + plane) * 64 + lane] = 8 bf16 = plane(W[32 (wave & 3) + (lane & 31)][kk .. kk + 7]),
+// kk = (wave >> 2) * KP/2 + 16 st + 8 (lane >> 5); zeros outside [out_dim, dim].  One thread per (wave, st, lane).
+template <int KP>
+__global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw, int dim, int out_dim, uint4* __restrict__ prepared) {
+    constexpr int KH = KP / 2, STEPS = KH / 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 8 * STEPS * 64) return;
+    const int lane = idx & 63, st = (idx >> 6) % STEPS, wave = idx / (64 * STEPS);
+    const int row = 32 * (wave & 3) + (lane & 31);
+    const int kk = (wave >> 2) * KH + 16 * st + 8 * (lane >> 5);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (row < out_dim) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kk + e < dim) v0[e] = W[(int64_t)row * ldw + kk + e];
+            if (kk + 4 + e < dim) v1[e] = W[(int64_t)row * ldw + kk + 4 + e];
+        }
+    }
+    bf16x4 h0, m0, l0, h1, m1, l1;
+    split3(v0, h0, m0, l0);
+    split3(v1, h1, m1, l1);
+    const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 pm = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    uint4* dst = prepared + ((size_t)(wave * STEPS + st) * 3) * 64 + lane;
+    dst[0] = __builtin_bit_cast(uint4, ph);
+    dst[64] = __builtin_bit_cast(uint4, pm);
+    dst[128] = __builtin_bit_cast(uint4, pl);
+}
+
+int prepared_kp(int32_t dim, int32_t out_dim) {
+    if (!sage_layer_dense_supported(dim, out_dim) || dim > 256) return 0;
+    return dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
+}
+
 }  // namespace
+
+// Prepared weights exist for the non-concat contraction with dim <= 256 (the one-pass kernel); 0 = this layer shape takes W as it is.
+extern "C" size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat) {
+    const int kp = concat ? 0 : prepared_kp(dim, out_dim);
+    return kp ? (size_t)8 * (kp / 32) * 3 * 64 * 16 : 0;
+}
+
+extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t out_dim, int32_t concat, void* prepared,
+                                    size_t prepared_bytes, sage_stream_t stream) {
+    SAGE_REQUIRE(weight && prepared, "prepare_weights: NULL argument");
+    const size_t need = sage_prepared_weight_bytes(dim, out_dim, concat);
+    if (need == 0) {
+        sage_set_error("prepare_weights: no prepared form for dim=%d out_dim=%d concat=%d", dim, out_dim, concat);
+        return SAGE_EUNSUPPORTED;
+    }
+    SAGE_REQUIRE(prepared_bytes >= need, "prepare_weights: buffer %zu bytes < %zu", prepared_bytes, need);
+    SAGE_REQUIRE(ldw >= dim && sage_aligned(prepared, 16), "prepare_weights: ldw = %lld, buffer alignment", (long long)ldw);
+    const int kp = prepared_kp(dim, out_dim);
+    const int threads = 8 * (kp / 32) * 64, blocks = sage_cdiv(threads, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (kp == 64) hipLaunchKernelGGL(prepare_weights_kernel<64>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
+    else if (kp == 128) hipLaunchKernelGGL(prepare_weights_kernel<128>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
+    else hipLaunchKernelGGL(prepare_weights_kernel<256>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
+    SAGE_CHECK_LAUNCH("prepare_weights_kernel");
+    return SAGE_OK;
+}
 
 bool sage_layer_dense_supported(int32_t dim, int32_t out_dim) {
     return dim >= 4 && dim % 4 == 0 && out_dim >= 1 && out_dim <= 128;
@@ -425,7 +681,7 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
                             const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
                             const int32_t* cnt, const int32_t* any_nonempty,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
-                            sage_finish_t fin, hipStream_t st) {
+                            sage_finish_t fin, const void* weight_prepared, hipStream_t st) {
     if (!sage_layer_dense_supported(dim, out_dim) || ldx % 4 != 0 || ldw % 4 != 0 || !sage_aligned(x, 16) ||
         !sage_aligned(weight, 16) || (concat && (ld_self % 4 != 0 || !sage_aligned(self_tab, 16)))) {
         sage_set_error("layer_dense: unsupported shape dim=%d out_dim=%d", dim, out_dim);
@@ -433,11 +689,17 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     }
     if (n == 0) return SAGE_OK;
     const DenseArgs a{x, ldx, dim, n, n_dev, n_off, concat ? self_tab : x, concat ? ld_self : ldx, concat ? (int)self_rows : n,
-                      self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin};
+                      self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin,
+                      (!concat && dim <= 256) ? (const uint4*)weight_prepared : nullptr};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
     if (dim > 256) return concat ? launch_bf16x3<256, true, true>(a, st) : launch_bf16x3<256, false, true>(a, st);
 #ifndef SAGE_DENSE_FP32
     if (!concat) {
+        if (sage_tunables().dense_variant == 1 && out_dim > 32) {       // small-footprint blocks (64 output columns each)
+            if (kp == 64) return launch_bf16x3_c64<64>(a, st);
+            if (kp == 128) return launch_bf16x3_c64<128>(a, st);
+            return launch_bf16x3_c64<256>(a, st);
+        }
         if (kp == 64) return launch_bf16x3<64, false>(a, st);
         if (kp == 128) return launch_bf16x3<128, false>(a, st);
         return launch_bf16x3<256, false>(a, st);

@@ -145,7 +145,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     SAGE_EV(0);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, m->num_nodes, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
                                     cnt2, (m->nan_empty && self_loop) ? any2 : nullptr, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
-                                    nullptr, cursor_off, key_slot, st))
+                                    nullptr, cursor_off, key_slot, m->seed_map, st))
         return rc;
     SAGE_EV(1);
     }
@@ -158,7 +158,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     SAGE_EV(2);
     if (int rc = sage_launch_sample(m->rowptr1, m->col1, m->num_nodes, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
                                     SAGE_TAG_INNER_SELF, nbr1, cnt1, m->nan_empty ? any1 : nullptr, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
-                                    &resolve, cursor_off, key_slot, st))
+                                    &resolve, cursor_off, key_slot, nullptr, st))
         return rc;
     SAGE_EV(3);
     }
@@ -177,7 +177,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     SAGE_EV(6);
     if (split1) {
         if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
-                                             s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, st))
+                                             s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, m->w1_prepared, st))
             return rc;
     } else if (fuse1) {
         if (int rc = sage_launch_layer_fused(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,

@@ -259,12 +259,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
 // groups fetch different neighbours (the sliced gather's trick) with the whole neighbour list in flight, and the
 // groups meet in xor-shuffles: counts+ids -> rows -> LDS -> MFMA is two dependent trips instead of seven.
 // Waves 0..7 own the 16-column output tiles; their W slices are requested before the gather and stay in VGPRs.
-template <int KP, bool CONCAT, int INFLIGHT>
-__global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
+template <int KP, bool CONCAT, int INFLIGHT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 4) void layer_tile16_kernel(const FusedArgs a) {
+    // WAVES = 16: one row per wave (fastest alone).  WAVES = 8: two rows per wave, 512-thread blocks -- half the wave
+    // slots and VGPRs per block, so the block finds room on a CU that other batches' kernels already share (sage_pipe.hip:
+    // a 1024-thread block needs 16 free wave slots and 384 VGPRs per SIMD on ONE CU and waited for whole gathers to drain).
     constexpr int M = 16;
+    constexpr int RW = M / WAVES;                  // rows per wave
     constexpr int CHUNKS = CONCAT ? 2 : 1;
     constexpr int LDA = KP + 4;
     constexpr int LG = KP / 4, NPI = 64 / LG;      // lanes per row, neighbours per wave-instruction
+    static_assert(WAVES == 16 || WAVES == 8, "tile16: 16 or 8 waves (at most two rows per wave)");
     __shared__ __attribute__((aligned(16))) float lds[CHUNKS * M * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nn = a.n;
@@ -302,17 +307,30 @@ __global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * M;
-        const int g = row0 + wave;
-        if (g < nn) {                              // wave-uniform; rows past nn are never stored
-            // the first 64 ids are requested together with the count (the list has a.k slots), not after it
-            int first_ids = (lane < a.k) ? a.nbr[(int64_t)g * a.k + lane] : 0;
-            const int c = __builtin_amdgcn_readfirstlane(a.cnt[g]);
-            int s = -1;
-            if (a.self_row) {
-                s = a.self_row[g];
-                if (a.slot_rows && s >= 0) s = a.slot_rows[s];
-                s = __builtin_amdgcn_readfirstlane(s);
+        // the first 64 ids of every row of the wave are requested together with the counts, not after them
+        int first_ids[RW], cs[RW], ss[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int g = row0 + wave + WAVES * rr;
+            first_ids[rr] = 0; cs[rr] = 0; ss[rr] = -1;
+            if (g < nn) {
+                first_ids[rr] = (lane < a.k) ? a.nbr[(int64_t)g * a.k + lane] : 0;
+                cs[rr] = a.cnt[g];
+                if (a.self_row) ss[rr] = a.self_row[g];
             }
+        }
+        // rows of a wave one after the other (not unrolled: two rows' loads in flight at once cost 32 more VGPRs, and
+        // this kernel's latency hides under another batch's gather; the register footprint does not)
+#pragma unroll 1
+        for (int rr = 0; rr < RW; ++rr) {
+            const int rt = wave + WAVES * rr;          // row inside the tile
+            const int g = row0 + rt;
+            if (g >= nn) continue;                     // wave-uniform; rows past nn are never stored
+            const int c = __builtin_amdgcn_readfirstlane(RW == 1 || rr == 0 ? cs[0] : cs[RW - 1]);
+            const int ids0 = (RW == 1 || rr == 0) ? first_ids[0] : first_ids[RW - 1];
+            int s = (RW == 1 || rr == 0) ? ss[0] : ss[RW - 1];
+            if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+            s = __builtin_amdgcn_readfirstlane(s);
             f32x4 sv = {0.f, 0.f, 0.f, 0.f};
             if (CONCAT && grp == NPI - 1 && col_ok) {
                 const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
             bool extra = s >= 0;
             for (int base = 0; base < c; base += kWave) {
                 const int m = min(kWave, c - base);
-                int myid = first_ids;
+                int myid = ids0;
                 if (base > 0) myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
                 if (lane >= m) myid = 0;
                 if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
@@ -354,8 +372,8 @@ __global__ __launch_bounds__(1024) void layer_tile16_kernel(const FusedArgs a) {
             if (ceff > 0) mean = acc * (1.0f / (float)ceff);
             else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; mean = f32x4{fill, fill, fill, fill}; }
             if (!col_ok) mean = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (grp == 0) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + wave) * LDA + c0) = mean;
-            if (CONCAT && grp == NPI - 1) *reinterpret_cast<f32x4*>(lds + wave * LDA + c0) = sv;
+            if (grp == 0) *reinterpret_cast<f32x4*>(lds + ((CHUNKS - 1) * M + rt) * LDA + c0) = mean;
+            if (CONCAT && grp == NPI - 1) *reinterpret_cast<f32x4*>(lds + rt * LDA + c0) = sv;
         }
         __syncthreads();
         if (mfma_wave) {
@@ -396,7 +414,10 @@ int launch_tile16(const FusedArgs& a, hipStream_t st) {
     constexpr int INFLIGHT = CONCAT ? 7 : SAGE_T16_INFLIGHT;
     const int tiles = sage_cdiv(a.n, 16);
     const int grid = min(tiles, sage_tunables().tile16_grid);
-    hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT>), dim3(grid), dim3(1024), 0, st, a);
+    if (sage_tunables().tile16_waves == 8)
+        hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT, 8>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT, 16>), dim3(grid), dim3(1024), 0, st, a);
     SAGE_CHECK_LAUNCH("layer_tile16_kernel");
     return SAGE_OK;
 }

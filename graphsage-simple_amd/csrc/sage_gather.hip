@@ -104,6 +104,45 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
                             (int)blockIdx.x, (int)gridDim.x);
 }
 
+using sage_gather_detail::gather_sliced_block_pipelined;
+
+template <int SL, int U, int R>
+__global__ __launch_bounds__(256) void gather_mean_sliced_pipe_kernel(
+    const float* __restrict__ table, int table_rows, int64_t ld, int dim,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
+    const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice) {
+    gather_sliced_block_pipelined<SL, U, R>(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo,
+                                         n_off, nslice, (int)blockIdx.x, (int)gridDim.x);
+}
+
+using sage_gather_detail::gather_sliced_block_rows;
+
+template <int SL, int TRIP, bool SLOT>
+__global__ __launch_bounds__(256) void gather_mean_rows_kernel(
+    const float* __restrict__ table, int table_rows, int64_t ld, int dim,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
+    const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice) {
+    gather_sliced_block_rows<SL, TRIP, SLOT>(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo,
+                                       n_off, nslice, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int SL, typename... A>
+void launch_rows(int blocks, bool slot, hipStream_t st, A... args) {
+    if (slot) hipLaunchKernelGGL((gather_mean_rows_kernel<SL, 8, true>), dim3(blocks), dim3(256), 0, st, args...);
+    else if (sage_tunables().gather_trip >= 16) hipLaunchKernelGGL((gather_mean_rows_kernel<SL, 16, false>), dim3(blocks), dim3(256), 0, st, args...);
+    else hipLaunchKernelGGL((gather_mean_rows_kernel<SL, 8, false>), dim3(blocks), dim3(256), 0, st, args...);
+}
+
+template <int SL, int U, typename... A>
+void launch_pipe(int blocks, hipStream_t st, A... args) {
+    const int rows = sage_tunables().gather_rows_in_flight;
+    if (rows >= 4) hipLaunchKernelGGL((gather_mean_sliced_pipe_kernel<SL, U, 4>), dim3(blocks), dim3(256), 0, st, args...);
+    else if (rows >= 2) hipLaunchKernelGGL((gather_mean_sliced_pipe_kernel<SL, U, 2>), dim3(blocks), dim3(256), 0, st, args...);
+    else hipLaunchKernelGGL((gather_mean_sliced_pipe_kernel<SL, U, 1>), dim3(blocks), dim3(256), 0, st, args...);
+}
+
 }  // namespace
 
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k) {
@@ -125,11 +164,39 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
         const int sl = SAGE_SLICE_LANES;
 #else
         constexpr bool kForce = false;
-        const int sl = (dim <= 128 && dim % 64 != 0) ? 32 : 16;
+        const int forced = sage_tunables().gather_slice_lanes;
+        const int sl = forced ? forced : ((dim <= 128 && dim % 64 != 0) ? 32 : 16);
 #endif
         (void)kForce;
         const int nslice = sage_cdiv(dim, sl * 4);
         const int blocks = nslice * (kNumCU * sage_tunables().gather_blocks_per_cu / nslice);
+        if (sage_tunables().gather_variant == 2) {
+            // one destination row per lane group (see sage_gather_body.h)
+            if (sl == 8) launch_rows<8>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            else if (sl == 32) launch_rows<32>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            else launch_rows<16>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            SAGE_CHECK_LAUNCH("gather_mean_rows_kernel");
+            return SAGE_OK;
+        }
+        if (sage_tunables().gather_variant == 1) {
+            // rows software-pipelined: every neighbour of a row in ONE trip (U wave-instructions of 64/sl neighbours), the
+            // next row's ids requested meanwhile.  U by fanout; lists longer than U x 64/sl take further trips.
+            const int per = kWave / sl, need = sage_cdiv(k, per);
+            if (sl == 8) {
+                if (need <= 2) launch_pipe<8, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+                else if (need <= 4) launch_pipe<8, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+                else launch_pipe<8, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            } else if (sl == 32) {
+                if (need <= 4) launch_pipe<32, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+                else launch_pipe<32, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            } else {
+                if (need <= 2) launch_pipe<16, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+                else if (need <= 4) launch_pipe<16, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+                else launch_pipe<16, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            }
+            SAGE_CHECK_LAUNCH("gather_mean_sliced_pipe_kernel");
+            return SAGE_OK;
+        }
         if (sl == 32)
             hipLaunchKernelGGL(gather_mean_sliced_kernel<32>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
                                n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);

@@ -22,7 +22,7 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
                        int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* queue_model,
                        int nodes_from_batch, int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off,
-                       const sage_resolve_t* resolve, int32_t cursor_off, uint64_t* key_slot, hipStream_t st);
+                       const sage_resolve_t* resolve, int32_t cursor_off, uint64_t* key_slot, const int32_t* seed_map, hipStream_t st);
 
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
@@ -53,7 +53,7 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
                             const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
                             const int32_t* cnt, const int32_t* any_nonempty,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
-                            sage_finish_t fin, hipStream_t st);
+                            sage_finish_t fin, const void* weight_prepared, hipStream_t st);
 
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                                 uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream);
@@ -61,10 +61,17 @@ int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t w
 // Launch-shape tunables, read ONCE from the environment (A/B runs on one box without rebuilding; defaults are the
 // measured optima recorded in DESIGN.md).  Every value is clamped to a safe range.
 struct sage_tunables_t {
-    int gather_blocks_per_cu;     // SAGE_G_PER_CU        sliced gather: 256-thread blocks per CU (1..8), default 8
-    int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 192
+    int gather_blocks_per_cu;     // SAGE_G_PER_CU        sliced gather: 256-thread blocks per CU (1..8), default 6
+    int gather_slice_lanes;       // SAGE_G_SLICE_LANES   0 = by row width (16 lanes = 256-B slices; 32 for narrow odd rows), or 8 / 16 / 32
+    int gather_rows_in_flight;    // SAGE_G_ROWS          pipelined gather: rows of a wave in flight together (1 / 2 / 4), default 1
+    int gather_trip;              // SAGE_G_TRIP          rows form: neighbours of a row requested per trip (8 / 16), default 16
+    int gather_variant;           // SAGE_G_VARIANT       0 = three-trip rows, 1 = rows software-pipelined (default), 2 = one row per lane group
+    int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 256
+    int dense_variant;            // SAGE_DENSE_VARIANT   0 = 512-thread blocks x 128 columns, 1 = 256-thread blocks x 64 columns (non-concat)
+    int dense_prefetch;           // SAGE_DENSE_PREFETCH  variant 1: next tile's rows in flight during the MFMA loop (1) or not (0)
     int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 1024
     int tile16_grid;              // SAGE_T16_GRID        layer-2 tile16 kernel: max blocks (64..1024), default 512
+    int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks)
 };
 const sage_tunables_t& sage_tunables();
 

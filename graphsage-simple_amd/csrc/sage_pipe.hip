@@ -35,6 +35,9 @@ struct sage_pipe {
 
 namespace {
 enum { RS = 0, RG = 1, RD = 2, RL = 3 };
+// no timing, and no system-scope fence when an event completes: the hand-offs are device-to-device (agent scope is what the
+// next kernel's launch acquires anyway); a system fence per record is an L2 write-back on the stage's critical path
+constexpr unsigned kEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 
 int wait_on(sage_pipe* p, int consumer, int producer, int slot) {
     if (p->st[consumer] == p->st[producer]) return SAGE_OK;          // stream order already says it
@@ -83,14 +86,14 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     for (int r = 0; r < 4; ++r)
         for (int i = 0; i < depth; ++i) p->ev[r][i] = nullptr;
     p->ev_fork = nullptr;
-    if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&p->ev_fork, kEventFlags) != hipSuccess) {
         sage_set_error("pipe_create: hipEventCreate failed");
         delete p;
         return SAGE_ELAUNCH;
     }
     for (int r = 0; r < 4; ++r)
         for (int i = 0; i < depth; ++i)
-            if (hipEventCreateWithFlags(&p->ev[r][i], hipEventDisableTiming) != hipSuccess) {
+            if (hipEventCreateWithFlags(&p->ev[r][i], kEventFlags) != hipSuccess) {
                 sage_set_error("pipe_create: hipEventCreate failed");
                 sage_pipe_destroy(p);
                 return SAGE_ELAUNCH;
@@ -109,17 +112,19 @@ extern "C" int sage_pipe_destroy(sage_pipe_t* p) {
     return SAGE_OK;
 }
 
-extern "C" int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2) {
+extern "C" int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2, const void* w1_prepared) {
     SAGE_REQUIRE(p && w1 && w2, "pipe_update_weights: NULL argument");
     p->model.w1 = w1;
     p->model.w2 = w2;
+    p->model.w1_prepared = w1_prepared;
     return SAGE_OK;
 }
 
 // One batch through the four role streams.  `first_in_segment`: no earlier submit of this pipe is outstanding on the
 // slot (a fresh pipe, or the first `depth` submits inside a stream capture, where the captured graph itself orders
 // replays): the workspace-release wait is skipped.
-static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot) {
+static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot,
+                      void* const* gather_events = nullptr) {
     const int slot = (int)(p->submitted % (uint64_t)p->depth);
     const sage_model_t* m = &p->model;
     void* ws = p->ws[slot];
@@ -132,7 +137,9 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     if (int rc = record(p, RS, slot, p->st[RG] != p->st[RS])) return rc;
     // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
     if (int rc = wait_on(p, RG, RS, slot)) return rc;
+    if (gather_events && gather_events[0] && hipEventRecord((hipEvent_t)gather_events[0], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG])) return rc;
+    if (gather_events && gather_events[1] && hipEventRecord((hipEvent_t)gather_events[1], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
     if (int rc = record(p, RG, slot, p->st[RD] != p->st[RG])) return rc;
     // D: the contraction (or the whole fused layer 1)
     if (int rc = wait_on(p, RD, RG, slot)) return rc;
@@ -150,6 +157,14 @@ extern "C" int sage_pipe_submit(sage_pipe_t* p, const int32_t* seeds, uint64_t k
     SAGE_REQUIRE(p && seeds && out, "pipe_submit: NULL argument");
     SAGE_REQUIRE(ldo >= p->model.h2, "pipe_submit: ldo = %lld < h2", (long long)ldo);
     return submit_one(p, seeds, key, out, ldo, p->submitted < (uint64_t)p->depth);
+}
+
+// The same with two caller-owned hipEvent_t recorded on stream G right before and right after the layer-1 gather launch
+// (bench.py: the dominant kernel's duration inside the running pipeline).
+extern "C" int sage_pipe_submit_profiled(sage_pipe_t* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, void* const* gather_events) {
+    SAGE_REQUIRE(p && seeds && out && gather_events, "pipe_submit_profiled: NULL argument");
+    SAGE_REQUIRE(ldo >= p->model.h2, "pipe_submit_profiled: ldo = %lld < h2", (long long)ldo);
+    return submit_one(p, seeds, key, out, ldo, p->submitted < (uint64_t)p->depth, gather_events);
 }
 
 // n batches in one call (one host loop, no per-batch crossing of the language boundary): batch i takes

@@ -68,7 +68,7 @@ int sage_launch_gather_plus_sample(const float* table, int64_t table_rows, int64
     const GatherArgs ga{table, (int)table_rows, ld, dim, nbr1, cnt1, k1, n1, n1_dev, self_row, any1, agg, ldo, n_off, nslice};
     const FrontierDev fd{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u, frontier->nodes, frontier->count,
                          frontier->max_nodes, frontier_row_off};
-    const BatchSrc bs{qm->queue, qm->queue_cursor, qm->queue_len, 1, nodes_copy, cursor_off, key_slot, (int)qm->num_nodes};
+    const BatchSrc bs{qm->queue, qm->queue_cursor, qm->queue_len, 1, nodes_copy, cursor_off, key_slot, qm->seed_map, (int)qm->num_nodes};
     const SampleArgs sa{rowptr2, col2, batch, k2, tag, nbr2, cnt2, any2, fd, insert_self, slot2, self_slot2, bs};
     if (sl == 32) launch_by_fanout<32>(k2, ga, sa, ngb, st);
     else launch_by_fanout<16>(k2, ga, sa, ngb, st);

@@ -91,11 +91,11 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
                        int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot, const sage_model_t* qm, int nodes_from_batch,
                        int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off, const sage_resolve_t* resolve,
-                       int32_t cursor_off, uint64_t* key_slot, hipStream_t st) {
+                       int32_t cursor_off, uint64_t* key_slot, const int32_t* seed_map, hipStream_t st) {
     if (n == 0) return SAGE_OK;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const BatchSrc bs{qm ? qm->queue : nullptr, qm ? qm->queue_cursor : nullptr, qm ? qm->queue_len : 0, nodes_from_batch, nodes_copy,
-                      cursor_off, key_slot, (int)num_nodes};
+                      cursor_off, key_slot, (qm && nodes_from_batch) ? qm->seed_map : seed_map, (int)num_nodes};
     ResolveJob rj{};
     if (resolve) rj = ResolveJob{resolve->slots, resolve->rows_out, resolve->n_slots, resolve->self_slots, resolve->self_rows_out,
                                  resolve->n_self, resolve->hash_rows, resolve->hash_keys};
@@ -138,7 +138,7 @@ extern "C" int sage_sample_neighbors(const int64_t* rowptr, const int32_t* col, 
         SAGE_REQUIRE(!insert_self || self_slot, "sample_neighbors: insert_self needs self_slot");
     }
     return sage_launch_sample(rowptr, col, num_nodes, nodes, n, n_dev, k, seed, tag, 0, tag, nbr, cnt, any_nonempty, frontier, insert_self,
-                              nbr_slot, self_slot, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, (hipStream_t)stream);
+                              nbr_slot, self_slot, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int32_t k, const int32_t* self_nodes, int32_t n,
@@ -156,7 +156,7 @@ extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int3
     const int32_t* no32 = nullptr;
     launch_by_fanout<false, true>(k, n, (hipStream_t)stream, no64, no32, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt,
                                   (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, fd, self_nodes ? 1 : 0, nbr_slot,
-                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0}, 0, ResolveJob{});
+                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0}, 0, ResolveJob{});
     SAGE_CHECK_LAUNCH("frontier_insert_kernel");
     return SAGE_OK;
 }

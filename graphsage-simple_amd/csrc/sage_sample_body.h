@@ -17,6 +17,7 @@ struct BatchSrc {
     int cursor_off;           // descriptor = queue[(*cursor + cursor_off) % len]  (pipelined forwards sample one batch ahead)
     uint64_t* key_slot;       // nullable: the outer hop leaves the sampler key here, the inner hop takes it from here
                               // instead of the queue (it then never reads the cursor, which another batch's last kernel advances)
+    const int32_t* seed_map;  // nullable: outer hop only -- nodes[r] is a CALLER id, seed_map[nodes[r]] the internal one
     int num_nodes;            // ids outside [0, num_nodes) are treated as isolated nodes (degree 0): the reference raises
                               // IndexError for them (nn.Embedding lookup); a device kernel must not walk rowptr[] with them.
                               // 0 = no check (callers that produced the ids themselves)
@@ -112,6 +113,7 @@ __device__ __forceinline__ void sample_block(
         int64_t s = 0, deg = 0;
         if (active) {
             v = nodes[r];
+            if (bs.seed_map) v = ((uint32_t)v < (uint32_t)bs.num_nodes) ? bs.seed_map[v] : -1;
             if (bs.nodes_copy && gl == 0) bs.nodes_copy[r] = v;
             if (bs.num_nodes == 0 || (uint32_t)v < (uint32_t)bs.num_nodes) {
                 s = rowptr[v];

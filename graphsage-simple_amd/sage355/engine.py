@@ -14,12 +14,16 @@ from .ops import ACT_RELU, _chk, _need_gpu, _row_major, as_ids
 
 class TwoHopEngine:
     def __init__(self, rowptr, col, table, w1, w2, k1, k2, concat=False, agg_self_loop=False, act1=ACT_RELU,
-                 act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None, relabel=None):
+                 act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None, relabel=None,
+                 prepare_weights=True):
         """rowptr/col: CSR of enc1.adj_lists (inner hop); rowptr_outer/col_outer: CSR of
         enc2.adj_lists when it differs (injected pre-sampled sets), default the same.
         w1 [h1, d0 | 2*d0], w2 [h2, h1 | 2*h1]: the Encoders' `weight` Parameters
         (referenced, not copied: an optimizer step is seen by the next forward)."""
         _need_gpu()
+        self._ctor = dict(rowptr=rowptr, col=col, table=table, w1=w1, w2=w2, k1=k1, k2=k2, concat=concat, agg_self_loop=agg_self_loop,
+                          act1=act1, act2=act2, nan_empty=nan_empty, fused=fused, max_batch=max_batch, rowptr_outer=rowptr_outer,
+                          col_outer=col_outer, relabel=relabel, prepare_weights=prepare_weights)
         self.rowptr1 = _chk(rowptr, torch.int64, "rowptr", 1)
         self.col1 = _chk(col, torch.int32, "col", 1)
         self.rowptr2 = self.rowptr1 if rowptr_outer is None else _chk(rowptr_outer, torch.int64, "rowptr_outer", 1)
@@ -28,8 +32,9 @@ class TwoHopEngine:
             raise native.SageError("inner and outer CSR must cover the same node ids")
         self.table, self.table_ld = _row_major(table, "table")
         # relabel="degree": work on a copy of graph and table renumbered by descending degree, so that the rows gathered
-        # most often are neighbours in memory (config 3: gather 45 -> 43 us, forward 81 -> 77 us).  Seeds are translated on
-        # the way in; ids in intermediates() are the INTERNAL ones (self.node_order[i] = caller's id of internal node i).
+        # most often are neighbours in memory (config 3: gather 46 -> 40 us).  The outer-hop kernel translates the seeds
+        # (model.seed_map), so the caller keeps its ids and outputs stay in the caller's seed order; ids in intermediates()
+        # are the INTERNAL ones (self.node_order[i] = caller's id of internal node i).
         # The device sampler is keyed by node id, so the sampled sets differ from the unrelabelled engine's (same law).
         self.node_order = self._new_of_old = None
         if relabel not in (None, "degree"):
@@ -57,6 +62,8 @@ class TwoHopEngine:
             self.table, self.table_ld = padded, self.d0p
         self._wpad_key = None
         self._w1p = self._w2p = None
+        self._w1prep = self._w1prep_key = None
+        self.prepare_weights = bool(prepare_weights)
         self.k1, self.k2 = int(k1), int(k2)
         self.concat, self.agg_self_loop = bool(concat), bool(agg_self_loop)
         self.act1, self.act2 = int(act1), int(act2)
@@ -100,8 +107,23 @@ class TwoHopEngine:
         self.table_ld = self.table.shape[1]
         self.node_order, self._new_of_old = order, new_of_old.to(torch.int32)
 
+    def sibling(self):
+        """Another engine over the SAME device graph / table / weights (shared, not copied) with a workspace of its own:
+        what every additional mini-batch in flight needs."""
+        if self._padded:                      # zero-padded copies of table / weights (small graphs): just build another
+            return TwoHopEngine(**self._ctor)
+        e = TwoHopEngine(self.rowptr1, self.col1, self.table, self.w1, self.w2, self.k1, self.k2, concat=self.concat,
+                         agg_self_loop=self.agg_self_loop, act1=self.act1, act2=self.act2, nan_empty=self.nan_empty, fused=self.fused,
+                         max_batch=self.max_batch, rowptr_outer=self.rowptr2, col_outer=self.col2, relabel=None,
+                         prepare_weights=self.prepare_weights)
+        e.node_order, e._new_of_old = self.node_order, self._new_of_old
+        e._model_key = None
+        return e
+
     def _seeds_in(self, seeds):
-        return seeds if self._new_of_old is None else self._new_of_old[seeds.long()]
+        """Seeds cross the boundary in the CALLER's ids; with relabel="degree" the outer-hop kernel translates them
+        (model.seed_map), inside the forward."""
+        return seeds
 
     def _weights(self):
         """The weight tensors the kernels read: the caller's own, or zero-padded copies kept in step with them."""
@@ -125,9 +147,27 @@ class TwoHopEngine:
         the widths are padded; `forward` does it by itself)."""
         self._model(queued=self._queue is not None)
 
+    def _prepare_w1(self, w1):
+        """enc1.weight split into bf16 planes in the contraction kernel's register order (sage_prepare_weights), redone
+        whenever the weight tensor or its version counter changes; None when this layer shape has no prepared form."""
+        L = native.lib()
+        need = L.sage_prepared_weight_bytes(self.d0p, self.h1p, int(self.concat))
+        if need == 0 or not self.prepare_weights:
+            return None
+        key = (w1.data_ptr(), w1._version)
+        if self._w1prep is None or self._w1prep.numel() != need:
+            self._w1prep = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._w1prep_key = None
+        if self._w1prep_key != key:
+            native.check(L.sage_prepare_weights(w1.data_ptr(), w1.stride(0), self.d0p, self.h1p, int(self.concat), self._w1prep.data_ptr(),
+                                                need, torch.cuda.current_stream().cuda_stream), "prepare_weights")
+            self._w1prep_key = key
+        return self._w1prep
+
     def _model(self, queued=False):
         w1, w2 = self._weights()
-        key = (w1.data_ptr(), w2.data_ptr(), self._queue.data_ptr() if self._queue is not None else 0)
+        prep = self._prepare_w1(w1.detach())
+        key = (w1.data_ptr(), w2.data_ptr(), self._queue.data_ptr() if self._queue is not None else 0, prep.data_ptr() if prep is not None else 0)
         if self._model_key == key:
             return self._model_q if queued else self._model_c
         _row_major(w1.detach(), "w1")
@@ -139,6 +179,8 @@ class TwoHopEngine:
             self.table.data_ptr(), self.table_ld, self.d0p, w1.data_ptr(), self.h1p, w2.data_ptr(), self.h2, self.k1, self.k2,
             int(self.concat), int(self.agg_self_loop), self.act1, self.act2, int(self.nan_empty), int(self.fused),
             int(self.max_batch))
+        self._model_c.w1_prepared = prep.data_ptr() if prep is not None else None
+        self._model_c.seed_map = self._new_of_old.data_ptr() if self._new_of_old is not None else None
         self._model_q = None
         if self._queue is not None:
             self._model_q = native.Model.from_buffer_copy(self._model_c)
@@ -296,8 +338,8 @@ class RolePipeline:
             raise native.SageError(f"RolePipeline: depth must be in [1, {native.PIPE_MAX_DEPTH}]")
         if len(roles) != 4:
             raise native.SageError("RolePipeline: roles is a 4-letter map of S, G, D, L onto streams, e.g. 'SGDL' or 'SGDD'")
-        self.engines = [TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=batch, **engine_kwargs) for _ in range(depth)]
-        e0 = self.engines[0]
+        e0 = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=batch, **engine_kwargs)
+        self.engines = [e0] + [e0.sibling() for _ in range(depth - 1)]
         self.device, self.batch, self.depth, self.h2 = e0.device, int(batch), int(depth), e0.h2
         names = []
         for ch in roles:
@@ -322,8 +364,9 @@ class RolePipeline:
     def _sync_weights(self):
         key = self._weights_key()
         if key != self._wkey:
-            w1, w2 = self.engines[0]._weights()
-            native.check(native.lib().sage_pipe_update_weights(self._h, w1.data_ptr(), w2.data_ptr()), "pipe_update_weights")
+            m = self.engines[0]._model()          # re-prepares the weight planes on the current stream
+            native.check(native.lib().sage_pipe_update_weights(self._h, m.w1, m.w2, m.w1_prepared), "pipe_update_weights")
+            self.fork()                           # the role streams wait for that
             self._wkey = key
 
     def __del__(self):
@@ -346,6 +389,14 @@ class RolePipeline:
         s = stream or torch.cuda.current_stream()
         native.check(native.lib().sage_pipe_join(self._h, s.cuda_stream), "pipe_join")
 
+    def submit_profiled(self, seeds, key, out, gather_events):
+        """submit() with two hipEvent_t (a ctypes c_void_p * 2) recorded on stream G around the layer-1 gather."""
+        self._sync_weights()
+        rc = native.lib().sage_pipe_submit_profiled(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(),
+                                                    out.stride(0), gather_events)
+        if rc != 0:
+            native.check(rc, "pipe_submit_profiled")
+
     def submit(self, seeds, key, out):
         """One batch: seeds int32 [batch] device tensor, out [batch, h2] fp32 device tensor (both must stay alive
         and unmodified until the batch has left the pipe: join() + synchronize, or an event on stream L)."""
@@ -355,7 +406,6 @@ class RolePipeline:
         if out.shape != (self.batch, self.h2) or out.dtype != torch.float32 or not out.is_cuda or out.stride(1) != 1:
             raise native.SageError("RolePipeline.submit: `out` must be a [batch, h2] fp32 device tensor with unit inner stride")
         self._sync_weights()
-        seeds = self.engines[0]._seeds_in(seeds)
         rc = native.lib().sage_pipe_submit(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), out.stride(0))
         if rc != 0:
             native.check(rc, "pipe_submit")
@@ -374,9 +424,6 @@ class RolePipeline:
                 or not out.is_contiguous() or out.shape[0] < min(self.depth, n)):
             raise native.SageError("RolePipeline.submit_many: `out` must be a contiguous [slots >= depth, batch, h2] fp32 device tensor")
         self._sync_weights()
-        if self.engines[0]._new_of_old is not None:
-            seeds = self.engines[0]._seeds_in(seeds).contiguous()
-            self._keep.append(seeds)
         karr = (ctypes.c_uint64 * n)(*[int(k) & 0xFFFFFFFFFFFFFFFF for k in keys])
         rc = native.lib().sage_pipe_submit_many(self._h, seeds.data_ptr(), self.batch, karr, n, out.data_ptr(), out.stride(1),
                                                 out.stride(0), out.shape[0], 1 if segment_start else 0)

@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
 TAG_INNER, TAG_OUTER, TAG_INNER_SELF = 1, 2, 3
 MAX_FANOUT = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 STAGE_SAMPLE_OUTER, STAGE_SAMPLE_INNER, STAGE_GATHER1, STAGE_CONTRACT1, STAGE_LAYER2 = 1, 2, 4, 8, 16
 
 # every symbol include/sage355.h declares (tests check the library exports each one)
@@ -25,7 +25,8 @@ SYMBOLS = [
     "sage_forward2_layout", "sage_forward2_init", "sage_forward2", "sage_forward2_profiled", "sage_forward2_stages",
     "sage_forward2_gather_sample",
     "sage_linear_act_backward", "sage_gather_mean_backward",
-    "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_many",
+    "sage_prepared_weight_bytes", "sage_prepare_weights",
+    "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_profiled", "sage_pipe_submit_many",
     "sage_pipe_join", "sage_pipe_fork",
 ]
 PIPE_MAX_DEPTH = 8
@@ -46,7 +47,7 @@ class Model(Structure):
                 ("w1", c_void_p), ("h1", c_int32), ("w2", c_void_p), ("h2", c_int32),
                 ("k1", c_int32), ("k2", c_int32), ("concat", c_int32), ("agg_self_loop", c_int32),
                 ("act1", c_int32), ("act2", c_int32), ("nan_empty", c_int32), ("fused", c_int32), ("ws_batch", c_int32),
-                ("queue", c_void_p), ("queue_len", c_int32), ("queue_cursor", c_void_p)]
+                ("queue", c_void_p), ("queue_len", c_int32), ("queue_cursor", c_void_p), ("w1_prepared", c_void_p), ("seed_map", c_void_p)]
 
 
 class Batch(Structure):      # sage_batch_t, lives in device memory (16 bytes)
@@ -114,16 +115,21 @@ def lib():
     L.sage_linear_act_backward.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
                                            P, I64, P, I64, P]
     L.sage_gather_mean_backward.argtypes = [P, I64, I32, P, P, I32, I32, P, P, P, P, I64, I64, P]
+    L.sage_prepared_weight_bytes.argtypes = [I32, I32, I32]
+    L.sage_prepare_weights.argtypes = [P, I64, I32, I32, I32, P, c_size_t, P]
     L.sage_pipe_create.argtypes = [POINTER(Model), I32, I32, POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_void_p)]
     L.sage_pipe_destroy.argtypes = [P]
-    L.sage_pipe_update_weights.argtypes = [P, P, P]
+    L.sage_pipe_update_weights.argtypes = [P, P, P, P]
     L.sage_pipe_submit.argtypes = [P, P, c_uint64, P, I64]
+    L.sage_pipe_submit_profiled.argtypes = [P, P, c_uint64, P, I64, POINTER(c_void_p)]
     L.sage_pipe_submit_many.argtypes = [P, P, I64, POINTER(c_uint64), I32, P, I64, I64, I32, I32]
     L.sage_pipe_join.argtypes = [P, P]
     L.sage_pipe_fork.argtypes = [P, P]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("sage_last_error", "sage_build_arch"):
+        if name == "sage_prepared_weight_bytes":
+            fn.restype = c_size_t
+        elif name not in ("sage_last_error", "sage_build_arch"):
             fn.restype = c_int32
     _lib = L
     return L

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 1
+#define SAGE_ABI_VERSION 2
 
 #define SAGE_OK            0
 #define SAGE_EINVAL       -1   /* bad argument (NULL, size, alignment, range) */
@@ -237,6 +237,13 @@ typedef struct {
     const sage_batch_t* queue;  /* [queue_len] descriptors in device memory            */
     int32_t        queue_len;
     int32_t*       queue_cursor;/* [1] device counter, advanced by one per forward      */
+    /* optional (ABI 2): enc1.weight already split into bf16 planes by sage_prepare_weights (NULL = the kernel
+     * splits its slice itself at every launch).  Must be refreshed whenever w1 changes (an optimizer step). */
+    const void*    w1_prepared;
+    /* optional (ABI 2): caller id -> internal id, int32[num_caller_ids].  An engine that keeps graph and table in an
+     * order of its own (sage355.engine: rows sorted by descending degree, so that the most-gathered feature rows are
+     * neighbours in HBM) translates every seed with it INSIDE the outer-hop kernel; NULL = ids are used as they are. */
+    const int32_t* seed_map;
 } sage_model_t;
 
 /* Where the intermediates of one forward live inside the caller's workspace
@@ -316,6 +323,19 @@ int sage_forward2_gather_sample(const sage_model_t* m, void* ws_cur, void* ws_ne
                                 int32_t cursor_offset, sage_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Weight preparation for the layer-1 contraction (encoders.py:58-61, `self.weight.mm(combined.t())`).
+ * The contraction runs on the bf16 matrix pipe with fp32 accuracy: x.w = sum over the products of the three
+ * bf16 terms of x and of w (csrc/sage_dense.hip).  Splitting W [out_dim, dim] into its three bf16 planes,
+ * laid out in the kernel's register order, depends only on W, so it can be done once per weight update instead
+ * of by every block of every launch (a third of the contraction's time at BASELINE config 3).
+ * sage_prepared_weight_bytes: size of the prepared form, 0 if this layer shape has none (concat encoder or
+ * dim > 256: W is then used as it is).  Results are bit-identical with and without the prepared form.
+ * ------------------------------------------------------------------------- */
+size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat);
+int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t out_dim, int32_t concat,
+                         void* prepared, size_t prepared_bytes, sage_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Role pipeline: consecutive forwards software-pipelined over ROLE STREAMS (csrc/sage_pipe.hip).
  * Each stage of the forward -- S: outer + inner sample, G: layer-1 gather, D: layer-1 contraction,
  * L: layer 2 -- is enqueued on a HIP stream of its own and consecutive batches move through the
@@ -334,10 +354,14 @@ typedef struct sage_pipe sage_pipe_t;
 int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t depth, void* const* workspaces,
                      size_t workspace_bytes, const sage_stream_t* streams, sage_pipe_t** out);
 int sage_pipe_destroy(sage_pipe_t* p);
-/* The pipe keeps a COPY of *m; after an optimizer step that moved the weights elsewhere: */
-int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2);
+/* The pipe keeps a COPY of *m; after an optimizer step (new pointers and / or freshly prepared planes; the caller
+ * orders the role streams behind whatever wrote them, e.g. with sage_pipe_fork): */
+int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2, const void* w1_prepared);
 /* One batch: seeds int32[batch] and out float[batch, h2] must stay valid until the batch has left stream L. */
 int sage_pipe_submit(sage_pipe_t* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo);
+/* sage_pipe_submit + two caller-owned hipEvent_t (gather_events[0], [1]) recorded on stream G around the layer-1 gather. */
+int sage_pipe_submit_profiled(sage_pipe_t* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo,
+                              void* const* gather_events);
 /* n batches from one host loop: batch i reads seeds + i*seed_stride (elements), keys_host[i] (HOST array) and
  * writes out + (i % out_slots)*out_stride.  segment_start != 0: the first `depth` batches of this call find
  * their workspaces free (first call on a pipe, or the first call inside a stream capture). */
