@@ -207,12 +207,52 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x8 = __attribute__((ext_vector_type(8))) float;
 
+// |x| >= 2^127, +-Inf or NaN (exponent field 254 or 255): the three-term split is not exact there -- RNE to bf16 can
+// round the first term up to Inf, and Inf - Inf poisons the remainders -- so a tile (or a weight slice) that holds such a
+// value is recomputed by exact_row_dot below, a plain fp32 fma chain with torch.mm's Inf / NaN behaviour.
+__device__ inline bool huge4(const f32x4 x) {
+    bool h = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h |= (__float_as_uint(x[e]) & 0x7F800000u) >= 0x7F000000u;
+    return h;
+}
+
 __device__ inline void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
     hi = __builtin_convertvector(x, bf16x4);
     const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
     mid = __builtin_convertvector(r1, bf16x4);
     const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
     lo = __builtin_convertvector(r2, bf16x4);
+}
+
+// out[g][col] before the activation as an fp32 fma chain over k (the [self | agg] order of encoders.py:54): the slow, exact
+// form for tiles that hold |x| >= 2^127 / Inf / NaN (never taken on ordinary data: one LDS word per tile decides)
+__device__ inline float exact_row_dot(const DenseArgs& a, bool concat, int g, int col, bool nan_rule) {
+    const float* wrow = a.W + (int64_t)col * a.ldw;
+    float acc = 0.f;
+    int koff = 0;
+    if (concat) {
+        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+        const float* sr = a.self_tab + s * a.ld_self;
+        for (int k = 0; k < a.dim; ++k) acc = fmaf(sr[k], wrow[k], acc);
+        koff = a.dim;
+    }
+    if (nan_rule && a.cnt[g] == 0) return __builtin_nanf("");
+    const float* xr = a.x + (int64_t)g * a.ldx;
+    for (int k = 0; k < a.dim; ++k) acc = fmaf(xr[k], wrow[koff + k], acc);
+    return acc;
+}
+
+__device__ inline bool row_is_huge(const DenseArgs& a, bool concat, int g, bool nan_rule) {
+    bool h = nan_rule && a.cnt[g] == 0;
+    const float* xr = a.x + (int64_t)g * a.ldx;
+    for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(xr[k]) & 0x7F800000u) >= 0x7F000000u;
+    if (concat) {
+        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+        const float* sr = a.self_tab + s * a.ld_self;
+        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(sr[k]) & 0x7F800000u) >= 0x7F000000u;
+    }
+    return h;
 }
 
 // MP (KP = 256 only): rows wider than 256 -- every K chunk takes ceil(dim / 256) passes (Pubmed 500, Cora 1433+3 pad).
@@ -237,6 +277,10 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     constexpr int PLD = 128 + 4;                         // floats per row of a partial-sum plane (+16 B: conflict-free b128 reads)
     __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);                                   // [2][3][M][LDB]
     float* part = reinterpret_cast<float*>(lds_raw + (size_t)2 * 3 * PL * sizeof(__bf16));  // [2 K halves][M][PLD]
+    constexpr int kBadListCap = 28;
+    int* flags = reinterpret_cast<int*>(part + 2 * M * PLD);     // [0], [1]: the tile staged in buffer b holds a huge value; [2]: W does;
+                                                                 // [3]: tiles to redo exactly, [4..31]: their indices (all of the block's if more);
+                                                                 // [32 + 32 b + r]: row r of the tile staged in buffer b holds a huge value
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nn = a.n;
@@ -277,7 +321,20 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 }
             }
         };
-        auto stage_tile = [&](__bf16* buf) {                  // VGPRs -> split -> three bf16 LDS planes
+        int stage_seq = 0;                                    // stagings so far (block-uniform): the tag a "huge value" mark carries,
+                                                              // so that marks never have to be cleared (a clear would race the next staging)
+        auto stage_tile = [&](__bf16* buf, int bsel) {        // VGPRs -> split -> three bf16 LDS planes
+            ++stage_seq;
+            bool huge = false;
+#pragma unroll
+            for (int pc = 0; pc < PCH; ++pc)
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const bool hp = huge4(xr[pc][p]);
+                    if (hp) flags[32 + 32 * bsel + wave * RPW + p * RPP + sg] = stage_seq;     // same value from every lane of the row
+                    huge |= hp;
+                }
+            if (__any(huge) && lane == 0) flags[bsel] = stage_seq;
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc)
 #pragma unroll
@@ -292,6 +349,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 }
         };
 
+        if (tid < 96) flags[tid] = 0;                         // ordered before the first staging by the barrier below
+        __syncthreads();
         STAMP(0);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
@@ -316,6 +375,12 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                         for (int pl = 0; pl < 3; ++pl) {
                             const uint4 v = wp[(st * 3 + pl) * 64];
                             bw[st][pl] = __builtin_bit_cast(bf16x8, v);
+                            if (pl == 0) {                    // first-term plane: bf16 exponent field 254 / 255 <=> the fp32 value was huge
+                                const bool hg = ((v.x & 0x7F80u) >= 0x7F00u) | ((v.x & 0x7F800000u) >= 0x7F000000u) | ((v.y & 0x7F80u) >= 0x7F00u) |
+                                                ((v.y & 0x7F800000u) >= 0x7F000000u) | ((v.z & 0x7F80u) >= 0x7F00u) | ((v.z & 0x7F800000u) >= 0x7F000000u) |
+                                                ((v.w & 0x7F80u) >= 0x7F00u) | ((v.w & 0x7F800000u) >= 0x7F000000u);
+                                if (__any(hg) && lane == 0) flags[2] = 1;
+                            }
                         }
                     return;
                 }
@@ -327,6 +392,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
                 if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc);
                 if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)chunk * a.dim + kc + 4);
+                if (__any(huge4(v0) || huge4(v1)) && lane == 0) flags[2] = 1;
                 bf16x4 h0, m0, l0, h1, m1, l1;
                 split3(v0, h0, m0, l0);
                 split3(v1, h1, m1, l1);
@@ -343,10 +409,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         int b = 0;
         for (int t0 = (int)blockIdx.x; t0 < ntiles; t0 += TG * stride) {
             f32x16 acc[TG];
+            int bad[TG];                                      // block-uniform: some value of tile t (any pass) or of W is huge
 #pragma unroll
-            for (int t = 0; t < TG; ++t)
+            for (int t = 0; t < TG; ++t) {
+                bad[t] = 0;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            }
             auto do_pass = [&](int pass) {
                 if (MULTI) {
                     // keep the scheduler from hoisting these loads above the previous pass's MFMAs: two live copies of
@@ -360,8 +429,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     const int tile = t0 + t * stride;
                     if (tile >= ntiles) continue;             // block-uniform
                     __bf16* buf = lds + b * 3 * PL;
-                    stage_tile(buf);
+                    stage_tile(buf, b);
                     __syncthreads();
+                    {   // bit 0: the tile (goes on the redo list); bits 1, 2: the two rows THIS thread stores in the epilogue; bit 3: W
+                        const int re = wave * (M / WAVES) + (lane >> 5);
+                        bad[t] |= (flags[b] == stage_seq ? 1 : 0) | (flags[32 + 32 * b + re] == stage_seq ? 2 : 0) |
+                                  (flags[32 + 32 * b + re + 2] == stage_seq ? 4 : 0) | (flags[2] != 0 ? 9 : 0);
+                    }
                     STAMP(stamp_i); ++stamp_i;
                     // the next work item's rows are in flight during the MFMA loop below
                     if (t + 1 < TG && tile + stride < ntiles) request_tile(tile + stride, pass);
@@ -408,6 +482,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     for (int reg = 0; reg < 16; ++reg) mine[((reg & 3) + 8 * (reg >> 2) + 4 * h) * PLD] = acc[t][reg];
                 }
                 __syncthreads();
+                if (tid == 0 && (bad[t] & 1)) { const int i = flags[3]++; if (i < kBadListCap) flags[4 + i] = tile; }   // only thread 0 touches these
 #pragma unroll
                 for (int it = 0; it < M / (WAVES * 2); ++it) {
                     const int row = wave * (M / WAVES) + 2 * it + (lane >> 5);
@@ -419,6 +494,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = sage_activate(p0[e] + p1[e], a.act);
+                        if (bad[t] & (8 | (2 << it))) continue;    // a row with a huge value (or huge W): redone exactly below; other rows of
+                                                                   // the tile keep the MFMA result, so a row never depends on its tile mates
                         float* dst = a.out + (int64_t)g * a.ldo + col;
                         if (col + 3 < a.out_dim && vec_store) {
                             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
@@ -433,163 +510,30 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
             }
         }
         STAMP(39);
-    }
-    sage_finish_block(a.fin, (int)gridDim.x);
-}
-
-
-// ---- the split-bf16 contraction in a SMALL footprint: 256-thread blocks that own 64 of the output columns ------------
-// dense_bf16x3_kernel above holds 352 of a SIMD's 512 VGPRs and 117 KB of LDS per block: it cannot share a CU with the
-// layer-1 gather of another batch (240-256 VGPRs per SIMD), so in the role pipeline (sage_pipe.hip) its blocks waited for
-// whole gathers to drain (rocprofv3 timeline: 24 us alone, 52-60 us beside a gather).  Here a block is 4 waves -- ONE per
-// SIMD -- that own output columns [64 c, 64 c + 64) (c = blockIdx & 1) as 2 column groups x 2 K halves; a wave's W slice
-// (32 columns x K/2, three bf16 planes) is the same 96 VGPRs, but a SIMD carries one such wave instead of two, the A tile
-// is single-buffered (48 KB) and each 32-row tile is staged by two blocks (once per column half; the second read is an
-// L2 / Infinity-Cache hit).  Same arithmetic, same summation order per output element as dense_bf16x3_kernel (K half 0
-// then + K half 1), so results are bit-identical to it.  Non-concat layers with dim <= 256 only.
-template <int KP, bool PREFETCH>
-__global__ __launch_bounds__(256) void dense_bf16x3_c64_kernel(const DenseArgs a) {
-    constexpr int M = 32, WAVES = 4;
-    constexpr int KH = KP / 2, STEPS = KH / 16;
-    constexpr int LDB = KP + 8;                          // bf16 elements per LDS row (+16 B: conflict-free ds_read_b128)
-    constexpr int PL = M * LDB;                          // elements per plane
-    constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / WAVES, PASSES = RPW / RPP;
-    static_assert(RPW % RPP == 0 && KH % 16 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);                                        // [3][M][LDB]
-    float* red = reinterpret_cast<float*>(lds_raw + (size_t)3 * PL * sizeof(__bf16));      // [2][16][64]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int nn = a.n;
-    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
-    const int ntiles = (nn + M - 1) / M;
-    const int chalf = (int)(blockIdx.x & 1), stride = (int)(gridDim.x >> 1);
-    const int first = (int)(blockIdx.x >> 1);
-    if (first < ntiles) {
-        const bool nan_rule = (a.cnt && a.any_nonempty) ? (*a.any_nonempty != 0) : false;
-        const int i32 = lane & 31, h = lane >> 5;
-        const int cgrp = wave & 1, kgroup = wave >> 1;
-        const int n0 = chalf * 64 + cgrp * 32;
-        const bool mfma_wave = n0 < a.out_dim;
-        const int lg = lane & (LG - 1), sg = lane / LG;
-        const int c0 = lg * 4;
-
-        f32x4 xr[PASSES];
-        auto request_tile = [&](int tile) {                  // global -> VGPRs, no wait
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int g = tile * M + wave * RPW + p * RPP + sg;
-                xr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (g < nn && c0 < a.dim) {
-                    xr[p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + c0);
-                    if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[p] = f32x4{q, q, q, q}; }
+        // Tiles that held |x| >= 2^127 / Inf / NaN (or all tiles, when W does): the exact fp32 fma chain, outside the loop above
+        // so that it costs the ordinary path no register.  Block-uniform; zero iterations on ordinary data.
+        __syncthreads();
+        const int nbad = flags[3];
+        if (nbad > 0) {
+            const bool all = nbad > kBadListCap || flags[2] != 0;
+            const int per = M * a.out_dim;
+            for (int tb = (int)blockIdx.x, li = 0; all ? (tb < ntiles) : (li < nbad); tb += stride, ++li) {
+                const int tile = all ? tb : flags[4 + li];
+                for (int idx = tid; idx < per; idx += (int)blockDim.x) {
+                    const int g = tile * M + idx / a.out_dim, col = idx % a.out_dim;
+                    if (g < nn && (flags[2] != 0 || row_is_huge(a, CONCAT, g, nan_rule)))
+                        a.out[(int64_t)g * a.ldo + col] = sage_activate(exact_row_dot(a, CONCAT, g, col, nan_rule), a.act);
                 }
             }
-        };
-        auto stage_tile = [&]() {                            // VGPRs -> split -> three bf16 LDS planes
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int r = wave * RPW + p * RPP + sg;
-                bf16x4 hi, mid, lo;
-                split3(xr[p], hi, mid, lo);
-                __bf16* dst = lds + r * LDB + c0;
-                *reinterpret_cast<bf16x4*>(dst) = hi;
-                *reinterpret_cast<bf16x4*>(dst + PL) = mid;
-                *reinterpret_cast<bf16x4*>(dst + 2 * PL) = lo;
-            }
-        };
-        request_tile(first);                                 // travels while W is fetched and split
-
-        const bool wrow_ok = mfma_wave && (n0 + i32) < a.out_dim;
-        const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
-        bf16x8 bw[STEPS][3];
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int kc = kgroup * KH + 16 * st + 8 * h;
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-            if (wrow_ok && kc < a.dim) v0 = *reinterpret_cast<const f32x4*>(wrow + kc);
-            if (wrow_ok && kc + 4 < a.dim) v1 = *reinterpret_cast<const f32x4*>(wrow + kc + 4);
-            bf16x4 h0, m0, l0, h1, m1, l1;
-            split3(v0, h0, m0, l0);
-            split3(v1, h1, m1, l1);
-            bw[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            bw[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-            bw[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-
-        for (int tile = first; tile < ntiles; tile += stride) {
-            if (!PREFETCH && tile != first) request_tile(tile);
-            stage_tile();
-            __syncthreads();
-            if (PREFETCH && tile + stride < ntiles) request_tile(tile + stride);      // in flight during the MFMA loop
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            if (mfma_wave) {
-                const __bf16* abase = lds + i32 * LDB + kgroup * KH + 8 * h;
-#pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(abase + 16 * st);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(abase + PL + 16 * st);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(abase + 2 * PL + 16 * st);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw[st][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], acc, 0, 0, 0);
-                }
-            }
-            float* myred = red + cgrp * 16 * 64;              // K half 1 -> LDS -> K half 0
-            if (kgroup == 1) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) myred[e * 64 + lane] = acc[e];
-            }
-            __syncthreads();                                  // also: every wave has read the A tile
-            if (kgroup == 0) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] += myred[e * 64 + lane];
-                const int col = n0 + i32;
-                if (mfma_wave && col < a.out_dim) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int g = tile * M + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        if (g < nn) __builtin_nontemporal_store(sage_activate(acc[reg], a.act), &a.out[(int64_t)g * a.ldo + col]);
-                    }
-                }
-            }
-            // the next stage_tile overwrites the A planes (all waves are past the barrier above, so they have read them)
-            // and the next K-half hand-over overwrites `red`, which K half 0 has read before ITS next barrier
         }
     }
     sage_finish_block(a.fin, (int)gridDim.x);
-}
-
-template <int KP>
-int launch_bf16x3_c64(const DenseArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)3 * 32 * (KP + 8) * 2 + (size_t)2 * 16 * 64 * sizeof(float);
-    static bool configured = false;
-    const bool prefetch = sage_tunables().dense_prefetch != 0;
-    if (!configured) {
-        if (lds > 64 * 1024 && (hipFuncSetAttribute((const void*)dense_bf16x3_c64_kernel<KP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                                hipFuncSetAttribute((const void*)dense_bf16x3_c64_kernel<KP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)) {
-            sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
-            return SAGE_ELAUNCH;
-        }
-        configured = true;
-    }
-    // two blocks (column halves) per tile; an even grid
-    const int grid = 2 * min(sage_cdiv(a.n, 32), max(sage_tunables().dense_blocks, 2) / 2);
-    if (prefetch) hipLaunchKernelGGL((dense_bf16x3_c64_kernel<KP, true>), dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((dense_bf16x3_c64_kernel<KP, false>), dim3(grid), dim3(256), lds, st, a);
-    SAGE_CHECK_LAUNCH("dense_bf16x3_c64_kernel");
-    return SAGE_OK;
 }
 
 template <int KP, bool CONCAT, bool MP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
-    constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float);
+    constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
     static bool configured = false;
     if (!configured) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -695,11 +639,6 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     if (dim > 256) return concat ? launch_bf16x3<256, true, true>(a, st) : launch_bf16x3<256, false, true>(a, st);
 #ifndef SAGE_DENSE_FP32
     if (!concat) {
-        if (sage_tunables().dense_variant == 1 && out_dim > 32) {       // small-footprint blocks (64 output columns each)
-            if (kp == 64) return launch_bf16x3_c64<64>(a, st);
-            if (kp == 128) return launch_bf16x3_c64<128>(a, st);
-            return launch_bf16x3_c64<256>(a, st);
-        }
         if (kp == 64) return launch_bf16x3<64, false>(a, st);
         if (kp == 128) return launch_bf16x3<128, false>(a, st);
         return launch_bf16x3<256, false>(a, st);

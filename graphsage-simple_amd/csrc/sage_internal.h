@@ -67,8 +67,6 @@ struct sage_tunables_t {
     int gather_trip;              // SAGE_G_TRIP          rows form: neighbours of a row requested per trip (8 / 16), default 16
     int gather_variant;           // SAGE_G_VARIANT       0 = three-trip rows, 1 = rows software-pipelined (default), 2 = one row per lane group
     int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 256
-    int dense_variant;            // SAGE_DENSE_VARIANT   0 = 512-thread blocks x 128 columns, 1 = 256-thread blocks x 64 columns (non-concat)
-    int dense_prefetch;           // SAGE_DENSE_PREFETCH  variant 1: next tile's rows in flight during the MFMA loop (1) or not (0)
     int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 1024
     int tile16_grid;              // SAGE_T16_GRID        layer-2 tile16 kernel: max blocks (64..1024), default 512
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks)

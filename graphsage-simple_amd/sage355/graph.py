@@ -132,12 +132,23 @@ def read_edge_list(path, fmt="pairs"):
     return csr_from_edges(ia, ib, names.size, symmetric=True), names
 
 
-def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, cache_dir=None):
+def _accel_device(accel, big=True):
+    if accel is None:
+        return None
+    import torch
+    if accel == "auto":
+        return torch.device("cuda", torch.cuda.current_device()) if (big and torch.cuda.is_available()) else None
+    return torch.device(accel)
+
+
+def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, cache_dir=None, accel="auto"):
     """Graph500-parameter R-MAT generator: ``num_edges`` directed
     draws on 2**scale nodes, ``numpy.random.default_rng(seed)``, one uniform per
     level choosing the quadrant with probabilities (a, b, c, 1-a-b-c); self loops
     dropped, symmetrised, deduplicated.  Generated in chunks to bound memory;
-    ``cache_dir`` keeps the CSR as .npy files for later runs on the same box."""
+    ``cache_dir`` keeps the CSR as .npy files for later runs on the same box.
+    ``accel``: where the integer work on the (numpy-drawn) uniforms runs -- "auto" = the GPU when there is one and the
+    graph is big, None = numpy, or a torch device; the result is the same CSR bit for bit."""
     import os
     tag = f"rmat_s{scale}_e{num_edges}_a{a}_b{b}_c{c}_seed{seed}"
     if cache_dir is not None:
@@ -149,29 +160,65 @@ def rmat_graph(scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, chunk=1 << 24, 
                 pass                               # unreadable cache: regenerate
     rng = np.random.default_rng(seed)
     n = 1 << scale
-    keys = []
     t_ab, t_abc = np.float32(a + b), np.float32(a + b + c)
     t_a = np.float32(a)
-    done = 0
-    while done < num_edges:
-        m = min(chunk, num_edges - done)
-        src = np.zeros(m, dtype=np.int64)
-        dst = np.zeros(m, dtype=np.int64)
-        for _ in range(scale):
-            u = rng.random(m, dtype=np.float32)
-            sbit = u >= t_ab
-            dbit = ((u >= t_a) & ~sbit) | (u >= t_abc)
-            src = (src << 1) | sbit
-            dst = (dst << 1) | dbit
-        keep = src != dst
-        src, dst = src[keep], dst[keep]
-        keys.append(np.unique(np.concatenate([src * n + dst, dst * n + src])))
-        done += m
-    key = np.unique(np.concatenate(keys)) if len(keys) > 1 else keys[0]
-    src = key >> scale
-    dst = key & (n - 1)
-    rowptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(np.bincount(src, minlength=n), out=rowptr[1:])
+    dev = _accel_device(accel, big=num_edges >= 4_000_000)
+    if dev is not None:
+        # Same uniforms from the same numpy stream; only the integer work on them (bit assembly, symmetrise, sort-unique,
+        # row pointers) runs as torch ops on `dev` -- a sorted set of keys does not depend on who sorted it, so the CSR is
+        # identical to the numpy path's (tests/test_host_logic.py), in seconds instead of minutes at 128 M edges.
+        import torch
+        keys = []
+        done = 0
+        while done < num_edges:
+            m = min(chunk, num_edges - done)
+            src = torch.zeros(m, dtype=torch.int64, device=dev)
+            dst = torch.zeros(m, dtype=torch.int64, device=dev)
+            for _ in range(scale):
+                u = torch.from_numpy(rng.random(m, dtype=np.float32)).to(dev, non_blocking=False)
+                sbit = u >= float(t_ab)
+                dbit = ((u >= float(t_a)) & ~sbit) | (u >= float(t_abc))
+                src = (src << 1) | sbit
+                dst = (dst << 1) | dbit
+            keep = src != dst
+            src, dst = src[keep], dst[keep]
+            keys.append(torch.unique(torch.cat([src * n + dst, dst * n + src])))
+            del src, dst, keep
+            done += m
+        key = torch.unique(torch.cat(keys)) if len(keys) > 1 else keys[0]
+        del keys
+        src = key >> scale
+        col_t = (key & (n - 1)).to(torch.int32)
+        del key
+        rowptr_t = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr_t[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+        del src
+        rowptr, dst = rowptr_t.cpu().numpy(), col_t.cpu().numpy()
+        del rowptr_t, col_t
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+    else:
+        keys = []
+        done = 0
+        while done < num_edges:
+            m = min(chunk, num_edges - done)
+            src = np.zeros(m, dtype=np.int64)
+            dst = np.zeros(m, dtype=np.int64)
+            for _ in range(scale):
+                u = rng.random(m, dtype=np.float32)
+                sbit = u >= t_ab
+                dbit = ((u >= t_a) & ~sbit) | (u >= t_abc)
+                src = (src << 1) | sbit
+                dst = (dst << 1) | dbit
+            keep = src != dst
+            src, dst = src[keep], dst[keep]
+            keys.append(np.unique(np.concatenate([src * n + dst, dst * n + src])))
+            done += m
+        key = np.unique(np.concatenate(keys)) if len(keys) > 1 else keys[0]
+        src = key >> scale
+        dst = key & (n - 1)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(src, minlength=n), out=rowptr[1:])
     g = CSRGraph(rowptr, dst.astype(np.int32), n)
     if cache_dir is not None:
         # several ranks of one node generate the same graph at the same time (bench.py --gpus N): each writes its own

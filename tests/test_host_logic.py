@@ -175,3 +175,10 @@ def test_adjacency_cache_detects_in_place_mutation_and_is_bounded(monkeypatch):
     for a in keep:
         encoders._device_csr(a, 0, "cpu")
     assert len(encoders._csr_cache) == encoders._CSR_CACHE_MAX
+
+
+def test_rmat_accelerated_integer_path_gives_the_same_csr():
+    """rmat_graph(accel=...) runs the integer work on torch; the uniforms still come from numpy's stream, so the CSR is identical."""
+    a = G.rmat_graph(13, 150_000, seed=3, accel=None, chunk=1 << 16)
+    b = G.rmat_graph(13, 150_000, seed=3, accel="cpu", chunk=1 << 16)
+    assert np.array_equal(a.rowptr, b.rowptr) and np.array_equal(a.col, b.col) and a.col.dtype == b.col.dtype == np.int32
