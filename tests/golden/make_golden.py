@@ -253,7 +253,70 @@ def reference_f1_fixture(g_cora):
                                                                   fixture["f1_macro_mean"], fixture["f1_macro_std"]))
 
 
+def reference_f1_fixture_pubmed(g_pub):
+    """The same for Pubmed (run_model("pubmed", ...), model.py:184-259): real Pubmed-Diabetes topology (19717 nodes, 3 classes)
+    + synthesised 500-dim content (the .NODE.paper.tab file is not in the checkout), hidden 50 / 128, gcn encoders, and the
+    reference's EFFECTIVE fanout 10 / 10 (its `enc.num_samples = 10 / 25` assignments are no-ops: Encoder reads `num_sample`,
+    model.py:223-224).  Bounded so that it finishes on CPU: ONE epoch of the reference's descending `max` batches with
+    batch_size 1024 (16 steps over 15774 .. 414 nodes), three torch seeds."""
+    import json
+    import time
+    from graphsage.model import SupervisedGraphSage
+    from sage355.datasets import standin_citation
+    from sklearn.metrics import f1_score
+    n = g_pub.num_nodes
+    feat_data, labels = standin_citation(g_pub, num_classes=3, feat_dim=500, seed=0)
+    adj_lists = g_pub.to_adj_lists()
+    runs = []
+    for torch_seed in range(3):
+        torch.manual_seed(torch_seed)
+        np.random.seed(1)
+        random.seed(1)
+        features = torch.nn.Embedding(n, 500)
+        features.weight = torch.nn.Parameter(torch.FloatTensor(feat_data), requires_grad=False)
+        agg1 = MeanAggregator(features, cuda=True, feature_dim=100, num_nodes=n, initializer="None")
+        enc1 = quiet(Encoder, features, 500, 50, adj_lists, agg1, gcn=True, cuda=False, initializer="None")
+        agg2 = MeanAggregator(lambda nodes: enc1(nodes).t(), n, cuda=False)
+        enc2 = quiet(Encoder, lambda nodes: enc1(nodes).t(), enc1.embed_dim, 128, adj_lists, agg2, base_model=enc1, gcn=True, cuda=False)
+        model = SupervisedGraphSage(3, enc2)
+        rand_indices = np.random.permutation(n)
+        val = rand_indices[int(0.1 * n):int(0.2 * n)]
+        train = list(rand_indices[int(0.2 * n):])
+        opt = torch.optim.SGD(filter(lambda p: p.requires_grad, model.parameters()), lr=0.7)
+        times = []
+        for _ in range(1):
+            random.shuffle(train)
+            for batch in range(0, len(train), 1024):
+                batch_nodes = train[batch:max(len(train), batch + 1024)]
+                t0 = time.time()
+                opt.zero_grad()
+                loss = model.loss(batch_nodes, torch.LongTensor(labels[np.array(batch_nodes)]))
+                loss.backward()
+                opt.step()
+                times.append(time.time() - t0)
+        with torch.no_grad():
+            out = model.forward(val)
+        pred = out.data.numpy().argmax(axis=1)
+        runs.append({"torch_seed": torch_seed, "f1_micro": float(f1_score(labels[val], pred, average="micro")),
+                     "f1_macro": float(f1_score(labels[val], pred, average="macro")), "mean_batch_time": float(np.mean(times))})
+        print("reference Pubmed F1 run", runs[-1], flush=True)
+    fixture = {"dataset": "Pubmed-Diabetes.DIRECTED.cites.tab topology + sage355.datasets.standin_citation(num_classes=3, feat_dim=500, seed=0)",
+               "config": {"epochs": 1, "batch_size": 1024, "ref_batching": True, "lr": 0.7, "seed": 1, "hidden": [50, 128],
+                          "num_sample": [10, 10], "gcn": True},
+               "runs": runs,
+               "f1_micro_mean": float(np.mean([r["f1_micro"] for r in runs])), "f1_micro_std": float(np.std([r["f1_micro"] for r in runs])),
+               "f1_macro_mean": float(np.mean([r["f1_macro"] for r in runs])), "f1_macro_std": float(np.std([r["f1_macro"] for r in runs]))}
+    with open(os.path.join(HERE, "reference_f1_pubmed_standin.json"), "w") as fp:
+        json.dump(fixture, fp, indent=1)
+    print("reference Pubmed F1 micro %.4f +- %.4f, macro %.4f +- %.4f" % (fixture["f1_micro_mean"], fixture["f1_micro_std"],
+                                                                         fixture["f1_macro_mean"], fixture["f1_macro_std"]))
+
+
 def main():
+    if "--f1-pubmed-only" in sys.argv:
+        g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")
+        reference_f1_fixture_pubmed(g_pub)
+        return
     g_tiny = tiny_graph()
     gen = torch.Generator().manual_seed(0)
     t_tiny = torch.randn(12, 8, generator=gen)
@@ -283,6 +346,8 @@ def main():
     tfidf = torch.from_numpy((rs.random((19717, 500)) * (rs.random((19717, 500)) < 0.1)).astype(np.float32))
     two_layer_case("pubmed_gcn_10_25", g_pub, tfidf, rs.choice(19717, 6, replace=False), 10, 25, 50, 128, True, 8)
     two_layer_case("pubmed_concat_10_25", g_pub, tfidf, rs.choice(19717, 4, replace=False), 10, 25, 50, 128, False, 9)
+    if "--f1" in sys.argv or not os.path.exists(os.path.join(HERE, "reference_f1_pubmed_standin.json")):
+        reference_f1_fixture_pubmed(g_pub)
 
 
 if __name__ == "__main__":
