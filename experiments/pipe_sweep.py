@@ -2,6 +2,7 @@
 Each config = depth:roles:priorities (e.g. 4:SGDL:S-1,D-1,L-1).  Prints us/forward per config, plus the two-stream
 graph-replay baseline, and checks the pipe against TwoHopEngine bit for bit."""
 import argparse, os, sys, time, json
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "graphsage-simple_amd")]
 import numpy as np, torch

@@ -126,7 +126,7 @@ __device__ inline uint32_t sage_group_positions(bool floyd, int64_t deg, int k, 
 
 __device__ inline float sage_activate(float v, int act) {
     if (act == SAGE_ACT_RELU) return v < 0.f ? 0.f : v;             // NaN stays NaN (torch.relu)
-    if (act == SAGE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    if (act == SAGE_ACT_SIGMOID) return 1.f / (1.f + expf(-v));     // accurate expf (not __expf): torch.sigmoid to ~1e-7 over the fp32 range
     return v;
 }
 #endif

@@ -344,3 +344,17 @@ def test_bf16x3_contraction_propagates_inf_and_nan_like_torch_mm(prepare):
         fin = torch.isfinite(ref)
         rows_fin = fin.all(1)
         assert_close_rowmax(got[rows_fin], (x.double() @ wt.double().t())[rows_fin], what="rows without a non-finite value")
+
+
+def test_sigmoid_activation_matches_torch_over_the_fp32_range():
+    """the sigmoid switch (encoders.py:58-59) was pinned only by one 10-seed fixture.  linear_act with an identity
+    weight is act(x): compare with torch.sigmoid from -100 to 100 (saturation, the steep part, tiny arguments)."""
+    x = torch.cat([torch.linspace(-100, 100, 4001), torch.tensor([0.0, -0.0, 1e-8, -1e-8, 88.0, -88.0, 20.0, -20.0])])
+    n = x.numel()
+    pad = (-n) % 4
+    x = torch.cat([x, torch.zeros(pad)])
+    agg = x.view(-1, 4).contiguous().to(DEV)
+    w = torch.eye(4, device=DEV)
+    got = ops.linear_act(agg, w, act=ops.ACT_SIGMOID).cpu().view(-1)
+    want = torch.sigmoid(x.double())
+    assert (got.double() - want).abs().max().item() <= 2e-7
