@@ -83,7 +83,31 @@ for cfg in args.configs:
     # host enqueue cost alone: time the submit loop without waiting
     torch.cuda.synchronize(); t0 = time.perf_counter(); pipe.submit_many(seeds[:40], keys[:40], out); host_us = (time.perf_counter() - t0) / 40 * 1e6
     torch.cuda.synchronize()
-    res[cfg] = {"us_submit_many": round(us_many, 2), "us_submit_each": round(us_each, 2), "host_enqueue_us": round(host_us, 2), "bit_identical": ok}
+    # the same K batches captured as ONE hipGraph over the four role streams (fork -> submit_many -> join), launched once
+    us_graph = float("nan")
+    if os.environ.get("SWEEP_GRAPH"):
+        cap = torch.cuda.Stream()
+        def build(lo, hi):
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(cap):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g_, stream=cap):
+                    pipe.fork(cap)
+                    pipe.submit_many(seeds[lo:hi], keys[lo:hi], out, segment_start=True)
+                    pipe.join(cap)
+            return g_
+        try:
+            gw, gt = build(0, args.warmup), build(args.warmup, total)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(cap):
+                gw.replay(); torch.cuda.synchronize()
+                t0 = time.perf_counter(); gt.replay(); torch.cuda.synchronize()
+                us_graph = (time.perf_counter() - t0) / args.steps * 1e6
+            ok_g = all(bool(torch.equal(out[i % out.shape[0]], ref_eng.forward(seeds[i], seed=keys[i]))) for i in range(total - 3, total))
+            print(f"     one hipGraph over the role streams: {us_graph:.2f} us/forward  identical={ok_g}", flush=True)
+        except Exception as ex:
+            print("     graph capture failed:", repr(ex)[:300], flush=True)
+    res[cfg] = {"us_graph": us_graph, "us_submit_many": round(us_many, 2), "us_submit_each": round(us_each, 2), "host_enqueue_us": round(host_us, 2), "bit_identical": ok}
     print(f"pipe {cfg:28s}: {us_many:7.2f} us/forward (submit_many)  {us_each:7.2f} (submit each)  host enqueue {host_us:.1f} us  identical={ok}", flush=True)
     del pipe
 print(json.dumps(res))

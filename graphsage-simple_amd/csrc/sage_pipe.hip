@@ -16,6 +16,8 @@
 // roles on the same stream is skipped), so {S,G,D,L} = one stream degenerates to sage_forward2.
 // Results are bit-identical to sage_forward2 on the same (seeds, key): same kernels, same workspaces' layout.
 // The reference has no counterpart: model.py:240-252 runs one batch at a time on the host.
+#include <stdlib.h>
+
 #include <new>
 
 #include "sage_internal.h"
@@ -37,7 +39,11 @@ namespace {
 enum { RS = 0, RG = 1, RD = 2, RL = 3 };
 // no timing, and no system-scope fence when an event completes: the hand-offs are device-to-device (agent scope is what the
 // next kernel's launch acquires anyway); a system fence per record is an L2 write-back on the stage's critical path
-constexpr unsigned kEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+static unsigned event_flags() {
+    const char* v = getenv("SAGE_PIPE_SYSFENCE");      // diagnostic: keep the system-scope fence on event completion
+    return (v && *v == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
+#define kEventFlags event_flags()
 
 int wait_on(sage_pipe* p, int consumer, int producer, int slot) {
     if (p->st[consumer] == p->st[producer]) return SAGE_OK;          // stream order already says it
@@ -169,8 +175,8 @@ extern "C" int sage_pipe_submit_profiled(sage_pipe_t* p, const int32_t* seeds, u
 
 // n batches in one call (one host loop, no per-batch crossing of the language boundary): batch i takes
 // seeds + i*seed_stride, keys[i] and writes out + (i % out_slots) * out_stride.
-// segment_start != 0: treat the first `depth` batches as having fresh slots (use inside a stream capture, after
-// sage_pipe_join of the previous segment).
+// segment_start != 0: treat the first `depth` batches as having fresh slots (after sage_pipe_join + a synchronisation
+// of everything submitted before).
 extern "C" int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64_t seed_stride, const uint64_t* keys_host, int32_t n,
                                      float* out, int64_t ldo, int64_t out_stride, int32_t out_slots, int32_t segment_start) {
     SAGE_REQUIRE(p && seeds && keys_host && out, "pipe_submit_many: NULL argument");

@@ -346,8 +346,10 @@ int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t 
  * hipEvents; workspaces (each laid out by sage_forward2_layout and initialised by
  * sage_forward2_init for m->ws_batch / `batch`), streams and outputs belong to the caller.
  * streams[4] = {S, G, D, L}; entries may coincide (the event between two roles on one stream is
- * skipped).  All calls are host-side enqueues, capturable into a hipGraph between
- * sage_pipe_fork(origin) and sage_pipe_join(origin).  Not thread safe per pipe.
+ * skipped).  All calls are host-side enqueues (eleven stream operations per batch).  Capturing the four-stream
+ * pattern into ONE hipGraph (fork -> submits -> join) crashes inside hipStreamEndCapture on ROCm 7.2
+ * (experiments/pipe_sweep.py, SWEEP_GRAPH=1), so the pipe is driven eagerly; sage_pipe_fork / sage_pipe_join
+ * order it against the caller's own stream.  Not thread safe per pipe.
  * Replaces nothing in the reference (model.py:240-252 runs one batch at a time).
  * ------------------------------------------------------------------------- */
 #define SAGE_PIPE_MAX_DEPTH 8
@@ -365,7 +367,7 @@ int sage_pipe_submit_profiled(sage_pipe_t* p, const int32_t* seeds, uint64_t key
                               void* const* gather_events);
 /* n batches from one host loop: batch i reads seeds + i*seed_stride (elements), keys_host[i] (HOST array) and
  * writes out + (i % out_slots)*out_stride.  segment_start != 0: the first `depth` batches of this call find
- * their workspaces free (first call on a pipe, or the first call inside a stream capture). */
+ * their workspaces free (the caller has joined everything submitted before). */
 int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64_t seed_stride, const uint64_t* keys_host,
                           int32_t n, float* out, int64_t ldo, int64_t out_stride, int32_t out_slots,
                           int32_t segment_start);
