@@ -78,9 +78,6 @@ def parse():
     ap.add_argument("--batches-per-replay", type=int, default=0,
                     help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "
                          "whose 20 us of GPU work per batch is less than one graph launch costs the host)")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAGE_PIPELINE", "0")), choices=[0, 1, 2],
-                    help="software-pipelined replay (PipelinedEngine).  1: batch i+1 is sampled beside the contraction and layer 2 of "
-                         "batch i (graph branches); 2: its outer sample shares ONE launch with the gather of batch i")
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=16_000_000)
     ap.add_argument("--dim", type=int, default=256)
@@ -192,7 +189,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from sage355 import native
-    from sage355.engine import PipelinedEngine, RolePipeline, TwoHopEngine
+    from sage355.engine import RolePipeline, TwoHopEngine
     from sage355.graph import rmat_graph
     native.lib()
 
@@ -268,14 +265,11 @@ def main():
     #  replay          : hipGraph replay from a device batch queue, `streams` independent forwards in flight (round 1's mode)
     #  direct          : host-enqueued sage_forward2 calls
     exec_mode = args.exec
-    if args.pipeline:
-        exec_mode = "replay"
     bpr = args.batches_per_replay if args.batches_per_replay > 0 else (10 if args.config == 2 else 1)
     if args.config == 2 and args.exec == "pipe" and not args.exec_given:
         exec_mode = "replay"        # 256-seed batches: 20 us of GPU work per batch, less than the host's enqueue per batch
     pipe = None
-    engines, streams, outs, pipes = [], [], [], []
-    pipelined = False
+    engines, streams, outs = [], [], []
     if exec_mode == "pipe":
         pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, **ekw)
         pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
@@ -285,18 +279,7 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
         outs = [torch.empty(b, h2, device=dev) for _ in range(nstreams)]
         use_graph = exec_mode == "replay"
-        pipelined = bool(args.pipeline) and use_graph and args.warmup % (2 * nstreams) == 0 and args.steps % (2 * nstreams) == 0
-        if pipelined:
-            pair = np.arange(total_steps) // 2
-            for s in range(nstreams):
-                mine = np.nonzero(pair % nstreams == s)[0]
-                pe = PipelinedEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, mode="fused" if args.pipeline == 2 else "branches", **ekw)
-                pe.set_queue(seeds_dev[torch.from_numpy(mine).to(dev)].contiguous(), [sampler_seed[i] for i in mine])
-                with torch.cuda.stream(streams[s]):
-                    pe.capture()
-                pipes.append(pe)
-            torch.cuda.synchronize()
-        elif use_graph:
+        if use_graph:
             if bpr > 1 and (args.warmup % (bpr * nstreams) or args.steps % (bpr * nstreams)):
                 bpr = 1                                   # the step counts must split into whole replays per stream
             group = np.arange(total_steps) // bpr
@@ -316,12 +299,6 @@ def main():
             # C loop at once (sage_pipe_submit_many), whose only difference is that the host runs further ahead of the GPU
             for i in step_range:
                 pipe.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
-            return
-        if pipelined:
-            for j in range(step_range.start // 2, step_range.stop // 2):      # one replay = steps 2j, 2j+1
-                s = j % nstreams
-                with torch.cuda.stream(streams[s]):
-                    pipes[s].replay()
             return
         if exec_mode == "replay" and bpr > 1:
             for j in range(step_range.start // bpr, step_range.stop // bpr):  # one replay = steps j*bpr .. j*bpr + bpr - 1
@@ -541,7 +518,7 @@ def main():
                                                                 "translated inside every timed forward)" if relabel else ""),
                        "contraction": "bf16x3-split MFMA (fp32-accurate: x.w from the three bf16 terms of x and of w; weight planes prepared "
                                       "once per weight update by sage_prepare_weights)",
-                       "pipelined_sampling": pipelined, "batches_per_replay": 2 if pipelined else (bpr if exec_mode == "replay" else 1),
+                       "batches_per_replay": bpr if exec_mode == "replay" else 1,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
             "parity_max_err_vs_fp64_oracle": parity_err,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

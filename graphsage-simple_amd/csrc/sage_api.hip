@@ -38,6 +38,7 @@ const sage_tunables_t& sage_tunables() {
         const int so = env_int("SAGE_SO_THREADS", 1024, 256, 1024);
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);
+        x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);
         x.tile16_waves = env_int("SAGE_T16_WAVES", 8, 8, 16) >= 16 ? 16 : 8;
         return x;
     }();

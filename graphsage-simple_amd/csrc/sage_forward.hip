@@ -140,7 +140,24 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     const bool split1 = m->fused && L.layer1_split && sage_aligned(m->table, 16) && sage_aligned(m->w1, 16) &&
                         sage_gather_is_sliced(m->d0, m->table_ld, m->d0, m->table, agg1, L.max_s1, m->k1);
     uint64_t* key_slot = key_in_ws ? (uint64_t*)(counters + 16) : nullptr;    // in the 256-B slot of the counters, past the 16 ints in use
-    if (stages & SAGE_STAGE_SAMPLE_OUTER) {
+    // Layer 2 as a one-launch layer resolves hash slots itself, so both hops can be sampled by ONE launch (sage_sample.hip:
+    // sample_fused_kernel).  The choice depends on the model only, so every call on a workspace agrees on who resolves the slots.
+    const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat) && sage_aligned(m->w2, 16);
+    const bool sfused = fuse2 && sage_tunables().sample_fused != 0 && m->k1 <= 64 && m->k2 <= 64;
+    const int both = SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER;
+    if (sfused && (stages & both)) {
+        SAGE_REQUIRE((stages & both) == both, "forward2: with the fused sampler the two sampling stages are one launch: pass "
+                                                "SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER together");
+        SAGE_EV(0);
+        if (int rc = sage_launch_sample_fused(m, seeds, batch, seed, nbr2, cnt2, (m->nan_empty && self_loop) ? any2 : nullptr, &fr, self_loop, slot2,
+                                              self_slot2, queued ? 1 : 0, m->concat ? s1_nodes : nullptr, first_row, nbr1, cnt1,
+                                              m->nan_empty ? any1 : nullptr, m->concat ? batch : 0, st))
+            return rc;
+        SAGE_EV(1);
+        SAGE_EV(2);
+        SAGE_EV(3);
+    }
+    if (!sfused && (stages & SAGE_STAGE_SAMPLE_OUTER)) {
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, m->num_nodes, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
@@ -149,7 +166,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
         return rc;
     SAGE_EV(1);
     }
-    if (stages & SAGE_STAGE_SAMPLE_INNER) {
+    if (!sfused && (stages & SAGE_STAGE_SAMPLE_INNER)) {
     // 2. inner hop: S1 -> nbr1 (raw table rows; duplicates are served by L2 / Infinity Cache).  Its spare
     //    threads turn the outer hop's hash slots into frontier rows and wipe the used keys.
     //    (Drawing these samples inside the layer-1 gather instead was measured: the gather went from 48 to
@@ -197,8 +214,14 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     if (stages & SAGE_STAGE_LAYER2) {
     // 4. layer 2 on the seeds; its last block zeroes the counters and advances the batch queue
     SAGE_EV(8);
-    const bool fuse2 = m->fused && sage_layer_fused_supported(m->h1, m->h2, m->concat) && sage_aligned(m->w2, 16);
-    if (fuse2) {
+    if (fuse2 && sfused) {
+        // slots in, rows resolved (and left in row2 / self_row2), keys wiped: the duties the inner-hop launch had
+        const sage_slot_resolve_t rs{fr.keys, row2, self_loop ? self_row2 : nullptr};
+        if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, slot2, cnt2, m->k2, batch, nullptr, fr.rows,
+                                             self_loop ? self_slot2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
+                                             out, ldo, 0, fin, st, &rs))
+            return rc;
+    } else if (fuse2) {
         if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, row2, cnt2, m->k2, batch, nullptr, nullptr,
                                              self_loop ? self_row2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
                                              out, ldo, 0, fin, st))
@@ -234,44 +257,6 @@ extern "C" int sage_forward2_stages(const sage_model_t* m, void* workspace, size
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                                 uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream) {
     return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, (sage_stream_t)stream, nullptr, stages, 0, false);
-}
-
-// gather(batch at the cursor, workspace `cur`) + outer sample(next batch, workspace `next`) as ONE launch (sage_pipeline.hip)
-extern "C" int sage_forward2_gather_sample(const sage_model_t* m, void* ws_cur, void* ws_next, size_t workspace_bytes, int32_t batch,
-                                           int32_t cursor_offset, sage_stream_t stream) {
-    if (int rc = check_model(m)) return rc;
-    SAGE_REQUIRE(m->queue && m->queue_len >= 1 && m->queue_cursor, "forward2_gather_sample: needs a batch queue (model.queue)");
-    SAGE_REQUIRE(ws_cur && ws_next && ws_cur != ws_next && sage_aligned(ws_cur, 256) && sage_aligned(ws_next, 256),
-                 "forward2_gather_sample: two distinct 256-byte aligned workspaces");
-    SAGE_REQUIRE(batch >= 1 && (m->ws_batch == 0 || batch <= m->ws_batch) && cursor_offset >= 0, "forward2_gather_sample: batch = %d", batch);
-    sage_ws_layout_t L;
-    if (int rc = sage_forward2_layout(m, m->ws_batch ? m->ws_batch : batch, &L)) return rc;
-    if (L.total_bytes > workspace_bytes) {
-        sage_set_error("forward2_gather_sample: workspace %zu bytes < %zu needed", workspace_bytes, L.total_bytes);
-        return SAGE_ENOSPACE;
-    }
-    const bool split1 = m->fused && L.layer1_split && sage_aligned(m->table, 16) && sage_aligned(m->w1, 16);
-    if (split1) {
-        char* wc = (char*)ws_cur;
-        char* wn = (char*)ws_next;
-        int32_t* cc = (int32_t*)(wc + L.counters);
-        int32_t* cn = (int32_t*)(wn + L.counters);
-        const int self_loop = m->agg_self_loop ? 1 : 0;
-        const int first_row = m->concat ? batch : 0;
-        int32_t* s1_nodes_c = (int32_t*)(wc + L.s1_nodes);
-        int32_t* s1_nodes_n = (int32_t*)(wn + L.s1_nodes);
-        const sage_frontier_t fr{(int32_t*)(wn + L.hash_keys), (int32_t*)(wn + L.hash_rows), L.hash_capacity, s1_nodes_n, cn + 0, L.max_s1};
-        const int rc = sage_launch_gather_plus_sample(
-            m->table, m->num_nodes, m->table_ld, m->d0, (const int32_t*)(wc + L.nbr1), (const int32_t*)(wc + L.cnt1), m->k1, L.max_s1, cc + 0,
-            self_loop ? s1_nodes_c : nullptr, m->nan_empty ? cc + 2 : nullptr, (float*)(wc + L.agg1), m->d0, first_row,
-            m->rowptr2, m->col2, batch, m->k2, SAGE_TAG_OUTER, (int32_t*)(wn + L.nbr2), (int32_t*)(wn + L.cnt2),
-            (m->nan_empty && self_loop) ? cn + 1 : nullptr, &fr, self_loop, (int32_t*)(wn + L.slot2), (int32_t*)(wn + L.self_slot2), m,
-            m->concat ? s1_nodes_n : nullptr, first_row, cursor_offset, (uint64_t*)(cn + 16), (hipStream_t)stream);
-        if (rc != SAGE_EUNSUPPORTED) return rc;
-    }
-    // no fused launch for this shape: the two pieces one after the other
-    if (int rc = forward2_impl(m, ws_cur, workspace_bytes, nullptr, batch, 0, nullptr, 0, stream, nullptr, SAGE_STAGE_GATHER1, 0, true)) return rc;
-    return forward2_impl(m, ws_next, workspace_bytes, nullptr, batch, 0, nullptr, 0, stream, nullptr, SAGE_STAGE_SAMPLE_OUTER, cursor_offset, true);
 }
 
 extern "C" int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds,

@@ -36,6 +36,7 @@ struct FusedArgs {
     const float* W; int64_t ldw; int out_dim; int act;
     float* out; int64_t ldo;
     int n_off; sage_finish_t fin;
+    int32_t* wipe_keys; int32_t* rows_out; int32_t* self_rows_out;     // slot -> row resolve duties (sage_slot_resolve_t), nullable
 };
 
 // KP: padded K per chunk; M: rows per tile; WAVES: waves per block (all gather; waves (w&3, w>>2)
@@ -112,15 +113,24 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
                 int s = -1;
                 if (a.self_row) {
                     s = a.self_row[g];
-                    if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+                    if (a.slot_rows && s >= 0) {
+                        if (a.wipe_keys && lane == 0) a.wipe_keys[s] = -1;
+                        s = a.slot_rows[s];
+                    }
                     s = __builtin_amdgcn_readfirstlane(s);
+                    if (a.self_rows_out && lane == 0) a.self_rows_out[g] = s;
                 }
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 bool extra = s >= 0;
+                if (a.rows_out && c == 0 && lane < a.k) a.rows_out[(int64_t)g * a.k + lane] = -1;
                 for (int base = 0; base < c; base += kWave) {
                     const int m = min(kWave, c - base);
                     int myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
-                    if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                    if (a.slot_rows) {
+                        if (a.wipe_keys && lane < m) a.wipe_keys[max(myid, 0)] = -1;
+                        myid = a.slot_rows[max(myid, 0)];
+                        if (a.rows_out && base + lane < a.k) a.rows_out[(int64_t)g * a.k + base + lane] = lane < m ? myid : -1;
+                    }
                     if (extra && __any(lane < m && myid == s)) extra = false;      // aggregators.py:50-51: set union
                     myid = min(max(myid, 0), last_row);
                     for (int j0 = 0; j0 < m; j0 += INFLIGHT) {
@@ -166,14 +176,23 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
                 int s = -1;
                 if (valid && a.self_row) {
                     s = a.self_row[gq];
-                    if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+                    if (a.slot_rows && s >= 0) {
+                        if (a.wipe_keys && lg == 0) a.wipe_keys[s] = -1;
+                        s = a.slot_rows[s];
+                    }
+                    if (a.self_rows_out && lg == 0) a.self_rows_out[gq] = s;
                 }
+                if (valid && a.rows_out && c == 0 && lg < a.k) a.rows_out[(int64_t)gq * a.k + lg] = -1;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 bool extra = s >= 0;
                 for (int base = 0; __any(base < c); base += LG) {
                     const int m = max(0, min(LG, c - base));
                     int myid = (lg < m) ? a.nbr[(int64_t)gq * a.k + base + lg] : 0;
-                    if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                    if (a.slot_rows) {
+                        if (a.wipe_keys && lg < m) a.wipe_keys[max(myid, 0)] = -1;
+                        myid = a.slot_rows[max(myid, 0)];
+                        if (valid && a.rows_out && base + lg < a.k) a.rows_out[(int64_t)gq * a.k + base + lg] = lg < m ? myid : -1;
+                    }
                     const unsigned long long hit = __ballot(extra && lg < m && myid == s);
                     if ((hit >> (lane - lg)) & ((1ull << LG) - 1ull)) extra = false;
                     myid = min(max(myid, 0), last_row);
@@ -329,8 +348,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void layer_tile16_kernel(const Fused
             const int c = __builtin_amdgcn_readfirstlane(RW == 1 || rr == 0 ? cs[0] : cs[RW - 1]);
             const int ids0 = (RW == 1 || rr == 0) ? first_ids[0] : first_ids[RW - 1];
             int s = (RW == 1 || rr == 0) ? ss[0] : ss[RW - 1];
-            if (a.slot_rows && s >= 0) s = a.slot_rows[s];
+            if (a.slot_rows && s >= 0) {
+                if (a.wipe_keys && lane == 0) a.wipe_keys[s] = -1;
+                s = a.slot_rows[s];
+            }
             s = __builtin_amdgcn_readfirstlane(s);
+            if (a.self_rows_out && lane == 0) a.self_rows_out[g] = s;
             f32x4 sv = {0.f, 0.f, 0.f, 0.f};
             if (CONCAT && grp == NPI - 1 && col_ok) {
                 const int64_t sr = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
@@ -338,12 +361,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void layer_tile16_kernel(const Fused
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             bool extra = s >= 0;
+            if (a.rows_out && c == 0 && lane < a.k) a.rows_out[(int64_t)g * a.k + lane] = -1;
             for (int base = 0; base < c; base += kWave) {
                 const int m = min(kWave, c - base);
                 int myid = ids0;
                 if (base > 0) myid = (lane < m) ? a.nbr[(int64_t)g * a.k + base + lane] : 0;
                 if (lane >= m) myid = 0;
-                if (a.slot_rows) myid = a.slot_rows[max(myid, 0)];
+                if (a.slot_rows) {
+                    if (a.wipe_keys && lane < m) a.wipe_keys[max(myid, 0)] = -1;          // this forward's key: gone for the next one
+                    myid = a.slot_rows[max(myid, 0)];
+                    if (a.rows_out && base + lane < a.k) a.rows_out[(int64_t)g * a.k + base + lane] = lane < m ? myid : -1;
+                }
                 if (extra && __any(lane < m && myid == s)) extra = false;          // aggregators.py:50-51: set union
                 myid = min(max(myid, 0), last_row);
                 for (int j0 = 0; j0 < m; j0 += NPI * INFLIGHT) {
@@ -483,7 +511,7 @@ int sage_launch_layer_fused(const float* table, int64_t table_rows, int64_t ld, 
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, int32_t concat, const int32_t* self_index,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo,
-                            int32_t n_off, sage_finish_t fin, hipStream_t st) {
+                            int32_t n_off, sage_finish_t fin, hipStream_t st, const sage_slot_resolve_t* resolve) {
     if (!sage_layer_fused_supported(dim, out_dim, concat) || ld % 4 != 0 || ldw % 4 != 0 || !sage_aligned(table, 16) ||
         !sage_aligned(weight, 16)) {
         sage_set_error("layer_forward: no fused kernel for dim=%d out_dim=%d ld=%lld (needs dim%%4==0, dim<=256, out_dim<=128, 16-B rows)",
@@ -492,7 +520,8 @@ int sage_launch_layer_fused(const float* table, int64_t table_rows, int64_t ld, 
     }
     if (n == 0) return SAGE_OK;
     const FusedArgs a{table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, self_index,
-                      table, ld, (int)table_rows, weight, ldw, out_dim, act, out, ldo, n_off, fin};
+                      table, ld, (int)table_rows, weight, ldw, out_dim, act, out, ldo, n_off, fin,
+                      resolve ? resolve->wipe_keys : nullptr, resolve ? resolve->rows_out : nullptr, resolve ? resolve->self_rows_out : nullptr};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
     if (!concat) {
         if (kp == 64) return launch_by_rows<64, false>(a, st);
@@ -520,5 +549,5 @@ extern "C" int sage_layer_forward(const float* table, int64_t table_rows, int64_
     SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "layer_forward: act = %d", act);
     return sage_launch_layer_fused(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, concat,
                                    self_index, weight, ldw, out_dim, act, out, ldo, 0, sage_finish_t{nullptr, nullptr},
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, nullptr);
 }

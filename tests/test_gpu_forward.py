@@ -16,7 +16,7 @@ from oracle import ref_sparse, sampler_ref
 from sage355 import ops
 from sage355.aggregators import MeanAggregator
 from sage355.encoders import Encoder
-from sage355.engine import PipelinedEngine, TwoHopEngine
+from sage355.engine import TwoHopEngine
 from sage355.graph import CSRGraph, rmat_graph
 from util import TWO_LAYER_CASES, assert_close_rowmax, full_table, load_golden, sets_from_padded
 
@@ -381,40 +381,6 @@ def test_graph_replay_of_queued_batches_equals_direct_calls():
                 assert torch.equal(out3[j], want[(first + j) % 5]), f"concat={concat} multi-batch replay, batch {(first + j) % 5}"
 
 
-@pytest.mark.parametrize("mode", ["branches", "fused"])
-@pytest.mark.parametrize("concat,self_loop,d0", [(False, False, 256), (True, False, 256), (False, True, 100), (True, True, 64)])
-def test_pipelined_replay_equals_direct_calls(concat, self_loop, d0, mode):
-    """sage_forward2_stages / PipelinedEngine: sampling batch i+1 beside the contraction and layer 2 of batch i (two
-    workspaces, parallel graph branches) must give, batch for batch, the bits of the plain forward -- over several
-    replays (each embeds two batches), around the ring, and after a rewind."""
-    graph = rmat_graph(14, 300_000, seed=2)
-    gen = torch.Generator().manual_seed(3)
-    m = 2 if concat else 1
-    table = torch.randn(graph.num_nodes, d0, generator=gen).to(DEV)
-    w1 = (torch.randn(128, m * d0, generator=gen) / 16).to(DEV)
-    w2 = (torch.randn(96, m * 128, generator=gen) / 11).to(DEV)
-    rowptr, col = graph.to(DEV)
-    rs = np.random.default_rng(5)
-    nb = 6
-    seeds = torch.from_numpy(np.stack([rs.choice(graph.num_nodes, 600, replace=False) for _ in range(nb)]).astype(np.int32)).to(DEV)
-    keys = [11, 2**63 + 5, 13, 2**64 - 1, 17, 19]
-    direct = TwoHopEngine(rowptr, col, table, w1, w2, 15, 25, concat=concat, agg_self_loop=self_loop, max_batch=600)
-    want = [direct.forward(seeds[i], seed=keys[i]).clone() for i in range(nb)]
-    pipe = PipelinedEngine(rowptr, col, table, w1, w2, 15, 25, concat=concat, agg_self_loop=self_loop, max_batch=600, mode=mode)
-    pipe.set_queue(seeds, keys)
-    out = pipe.capture()
-    for rnd in range(2):                            # second round: the ring wraps around
-        for i in range(0, nb, 2):
-            pipe.replay()
-            torch.cuda.synchronize()
-            for j in (0, 1):
-                assert torch.equal(torch.nan_to_num(out[j], nan=-7.0), torch.nan_to_num(want[i + j], nan=-7.0)), \
-                    f"round {rnd} batch {i + j}"
-    pipe.rewind(3)
-    pipe.replay()
-    torch.cuda.synchronize()
-    for j, i in enumerate((3, 4)):
-        assert torch.equal(torch.nan_to_num(out[j], nan=-7.0), torch.nan_to_num(want[i], nan=-7.0)), f"after rewind, batch {i}"
 
 
 def test_integration_md_ctypes_stub():

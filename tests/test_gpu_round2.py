@@ -178,6 +178,8 @@ VARIANTS = [
     {"SAGE_G_VARIANT": "2", "SAGE_G_SLICE_LANES": "32"},
     {"SAGE_DENSE_BLOCKS": "512", "SAGE_T16_WAVES": "8", "SAGE_SO_THREADS": "256"},
     {"SAGE_DENSE_BLOCKS": "96", "SAGE_SO_THREADS": "512", "SAGE_T16_GRID": "128"},
+    {"SAGE_SAMPLE_FUSED": "1", "SAGE_T16_WAVES": "16"},
+    {"SAGE_SAMPLE_FUSED": "1", "SAGE_SO_THREADS": "512", "SAGE_T16_WAVES": "8"},
 ]
 
 
@@ -358,3 +360,43 @@ def test_sigmoid_activation_matches_torch_over_the_fp32_range():
     got = ops.linear_act(agg, w, act=ops.ACT_SIGMOID).cpu().view(-1)
     want = torch.sigmoid(x.double())
     assert (got.double() - want).abs().max().item() <= 2e-7
+
+
+@pytest.mark.parametrize("concat,self_loop", [(False, False), (True, True)])
+def test_fused_sampler_leaves_the_same_sets_and_rows(concat, self_loop, tmp_path):
+    """SAGE_SAMPLE_FUSED=1 (both hops in one launch, slots resolved by the layer-2 kernel): the sampled sets are a function of
+    (key, node, hop) only, so outputs must equal the two-launch sampler's up to the frontier's arbitrary row order -- compared
+    here through what does not depend on that order: per-seed outputs (bit for bit: every kernel downstream works per row)."""
+    script = tmp_path / "fused.py"
+    script.write_text(f"""
+import sys
+sys.path[:0] = [{REPO!r}, {REPO!r} + "/graphsage-simple_amd", {REPO!r} + "/tests"]
+import numpy as np, torch
+from sage355.engine import TwoHopEngine
+from sage355.graph import rmat_graph
+graph = rmat_graph(15, 600_000, seed=2, accel=None)
+gen = torch.Generator().manual_seed(0)
+concat, self_loop = {concat}, {self_loop}
+m = 2 if concat else 1
+table = torch.randn(graph.num_nodes, 128, generator=gen).cuda()
+w1 = (torch.randn(128, m * 128, generator=gen) / 16).cuda(); w2 = (torch.randn(64, m * 128, generator=gen) / 11).cuda()
+rp, cl = graph.to("cuda")
+seeds = torch.from_numpy(np.random.default_rng(1).choice(np.nonzero(graph.degrees() > 0)[0], 2048, replace=False).astype(np.int32)).cuda()
+eng = TwoHopEngine(rp, cl, table, w1, w2, 15, 25, concat=concat, agg_self_loop=self_loop, max_batch=2048)
+out = eng.forward(seeds, seed=5)
+it = eng.intermediates()
+torch.save(dict(out=out.cpu(), nbr2=it["nbr2"].cpu(), cnt2=it["cnt2"].cpu(), s1=torch.sort(it["s1_nodes"].cpu()).values,
+                rows_ok=bool(((it["row2"] >= 0) == (it["nbr2"] >= 0)).all())), sys.argv[1])
+""")
+    res = {}
+    for fused in ("0", "1"):
+        e = dict(os.environ)
+        e["SAGE_SAMPLE_FUSED"] = fused
+        path = str(tmp_path / f"r{fused}.pt")
+        r = subprocess.run([sys.executable, str(script), path], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[fused] = torch.load(path, weights_only=True)
+    a, b = res["0"], res["1"]
+    assert torch.equal(a["nbr2"], b["nbr2"]) and torch.equal(a["cnt2"], b["cnt2"]) and torch.equal(a["s1"], b["s1"])
+    assert a["rows_ok"] and b["rows_ok"]
+    assert _eq(a["out"], b["out"])
