@@ -245,14 +245,6 @@ extern "C" int sage_forward2(const sage_model_t* m, void* workspace, size_t work
     return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, stream, nullptr);
 }
 
-extern "C" int sage_forward2_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t batch, float* out,
-                                    int64_t ldo, int32_t stages, int32_t cursor_offset, sage_stream_t stream) {
-    SAGE_REQUIRE(m && m->queue, "forward2_stages: needs a batch queue (model.queue)");
-    SAGE_REQUIRE(stages > 0 && stages <= SAGE_STAGE_ALL, "forward2_stages: stages = %d", stages);
-    SAGE_REQUIRE(cursor_offset >= 0, "forward2_stages: cursor_offset = %d", cursor_offset);
-    return forward2_impl(m, workspace, workspace_bytes, nullptr, batch, 0, out, ldo, stream, nullptr, stages, cursor_offset, true);
-}
-
 // A subset of the forward's launches with the seeds and the sampler key taken from the call (sage_pipe.hip: one call per role stream)
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                                 uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream) {

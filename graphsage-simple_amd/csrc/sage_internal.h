@@ -61,6 +61,13 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
                             sage_finish_t fin, const void* weight_prepared, hipStream_t st);
 
+// The launches of one forward, by stage (sage_pipe.hip enqueues each stage on its role stream)
+#define SAGE_STAGE_SAMPLE_OUTER 1
+#define SAGE_STAGE_SAMPLE_INNER 2
+#define SAGE_STAGE_GATHER1      4
+#define SAGE_STAGE_CONTRACT1    8     /* whole layer 1 when it is a one-launch layer */
+#define SAGE_STAGE_LAYER2       16
+#define SAGE_STAGE_ALL          31
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                                 uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream);
 

@@ -16,13 +16,12 @@ ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
 TAG_INNER, TAG_OUTER, TAG_INNER_SELF = 1, 2, 3
 MAX_FANOUT = 64
 ABI_VERSION = 2
-STAGE_SAMPLE_OUTER, STAGE_SAMPLE_INNER, STAGE_GATHER1, STAGE_CONTRACT1, STAGE_LAYER2 = 1, 2, 4, 8, 16
 
 # every symbol include/sage355.h declares (tests check the library exports each one)
 SYMBOLS = [
     "sage_abi_version", "sage_last_error", "sage_build_arch", "sage_frontier_reset", "sage_sample_neighbors",
     "sage_frontier_insert", "sage_gather_mean", "sage_linear_act", "sage_layer_forward", "sage_layer_forward_supported",
-    "sage_forward2_layout", "sage_forward2_init", "sage_forward2", "sage_forward2_profiled", "sage_forward2_stages",
+    "sage_forward2_layout", "sage_forward2_init", "sage_forward2", "sage_forward2_profiled",
     "sage_linear_act_backward", "sage_gather_mean_backward",
     "sage_prepared_weight_bytes", "sage_prepare_weights",
     "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_profiled", "sage_pipe_submit_many",
@@ -109,7 +108,6 @@ def lib():
     L.sage_forward2_init.argtypes = [POINTER(Model), P, c_size_t, I32, P]
     L.sage_forward2.argtypes = [POINTER(Model), P, c_size_t, P, I32, c_uint64, P, I64, P]
     L.sage_forward2_profiled.argtypes = [POINTER(Model), P, c_size_t, P, I32, c_uint64, P, I64, P, POINTER(c_void_p)]
-    L.sage_forward2_stages.argtypes = [POINTER(Model), P, c_size_t, I32, P, I64, I32, I32, P]
     L.sage_linear_act_backward.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
                                            P, I64, P, I64, P]
     L.sage_gather_mean_backward.argtypes = [P, I64, I32, P, P, I32, I32, P, P, P, P, I64, I64, P]

@@ -154,6 +154,7 @@ class EngineTrainer:
         self._native, self._ops = native, ops
         e = self.engine
         L = e.layout
+        dist.broadcast_params(self.parameters())             # data parallel: every rank starts from rank 0's weights
         self._nlive = torch.zeros(1, dtype=torch.int32, device=dev)
         self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=dev)
         self._agg1 = torch.zeros(L.max_s1, e.d0p, device=dev)
@@ -169,8 +170,10 @@ class EngineTrainer:
     def scores(self, seeds, key=0):
         return self.embed(seeds, key) @ self.w_cls.t()
 
-    def grads(self, seeds, labels, key):
-        """loss (device scalar) and the gradients of (w1, w2, w_cls) for one batch; nothing is updated."""
+    def grads(self, seeds, labels, key, global_batch=None):
+        """loss (device scalar) and the gradients of (w1, w2, w_cls) for one batch; nothing is updated.
+        global_batch: data parallel -- this rank holds a shard of a mini-batch of that many seeds; its loss is the SUM over its
+        shard / global_batch, so that the SUM of the ranks' gradients is the full-batch gradient."""
         native, ops, e = self._native, self._ops, self.engine
         lib = native.lib()
         st = native.stream_handle()
@@ -187,7 +190,10 @@ class EngineTrainer:
         # classifier + loss + their gradients: stock torch on the same stream (model.py:59-69)
         emb = out.detach().requires_grad_(True)
         w_cls = self.w_cls.detach().requires_grad_(True)
-        loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels)
+        if global_batch is None:
+            loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels)
+        else:
+            loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels, reduction="sum") / float(global_batch)
         g_out, g_cls = torch.autograd.grad(loss, (emb, w_cls))
         g_out = g_out.contiguous()
         w1p, w2p = e._weights()
@@ -230,9 +236,16 @@ class EngineTrainer:
             g_w1, g_w2 = g_w1p, g_w2p
         return loss.detach(), (g_w1, g_w2, g_cls)
 
-    def step(self, seeds, labels, key):
-        """forward + backward + SGD; -> loss as a device scalar (reading it is the caller's only synchronisation)."""
-        loss, (g1, g2, gc) = self.grads(seeds, labels, key)
+    def step(self, seeds, labels, key, global_batch=None):
+        """forward + backward + SGD; -> loss as a device scalar (reading it is the caller's only synchronisation).
+        With torch.distributed initialised (one process per GPU, backend "nccl" = RCCL over xGMI) the three weight gradients
+        travel in ONE flat all-reduce (SUM) per step, ~0.3 MB: latency bound, so one buffer and one call."""
+        loss, (g1, g2, gc) = self.grads(seeds, labels, key, global_batch)
+        if dist.world_size() > 1:
+            flat = torch.cat([g1.reshape(-1), g2.reshape(-1), gc.reshape(-1)])
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+            n1, n2 = g1.numel(), g2.numel()
+            g1, g2, gc = flat[:n1].view_as(g1), flat[n1:n1 + n2].view_as(g2), flat[n1 + n2:].view_as(gc)
         self.w1.add_(g1, alpha=-self.lr)
         self.w2.add_(g2, alpha=-self.lr)
         self.w_cls.add_(gc, alpha=-self.lr)

@@ -297,24 +297,6 @@ int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t worksp
                            float* out, int64_t ldo, sage_stream_t stream,
                            void* const* stage_events);
 
-/* A subset of the forward's five launches, for software-pipelining consecutive QUEUED batches over two
- * workspaces (sage355/engine.py: PipelinedEngine): the sampling of batch i+1 runs beside the contraction and
- * layer 2 of batch i as parallel branches of one captured graph,
- *     gather(i) -> [contract(i) | outer sample(i+1)] -> [layer 2(i) | inner sample(i+1)]
- * Requires m->queue.  `stages`: OR of SAGE_STAGE_*; the outer sample takes its descriptor from
- * queue[(*cursor + cursor_offset) % len] and leaves the sampler key in the workspace for the inner sample
- * (which therefore never reads the cursor, so it may run beside the previous batch's layer 2, whose last block
- * advances the cursor).  `out` is only used by SAGE_STAGE_LAYER2.  Results are bit-identical to sage_forward2.
- * Replaces nothing in the reference: model.py:240-249 processes one batch at a time. */
-#define SAGE_STAGE_SAMPLE_OUTER 1
-#define SAGE_STAGE_SAMPLE_INNER 2
-#define SAGE_STAGE_GATHER1      4
-#define SAGE_STAGE_CONTRACT1    8     /* whole layer 1 when it is a one-launch layer */
-#define SAGE_STAGE_LAYER2       16
-#define SAGE_STAGE_ALL          31
-int sage_forward2_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t batch,
-                         float* out, int64_t ldo, int32_t stages, int32_t cursor_offset, sage_stream_t stream);
-
 /* ---------------------------------------------------------------------------
  * Weight preparation for the layer-1 contraction (encoders.py:58-61, `self.weight.mm(combined.t())`).
  * The contraction runs on the bf16 matrix pipe with fp32 accuracy: x.w = sum over the products of the three

@@ -121,3 +121,44 @@ def test_engine_training_reaches_reference_f1_on_standin_pubmed():
     print(f"engine Pubmed F1 micro {mine:.4f} +- {spread:.4f} (runs {[round(m, 4) for m in micro]}), reference "
           f"{ref['f1_micro_mean']:.4f} +- {ref['f1_micro_std']:.4f}, tolerance {tol:.4f}")
     assert abs(mine - ref["f1_micro_mean"]) <= tol, (mine, ref["f1_micro_mean"], tol)
+
+
+def _dp_rank(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from sage355 import dist
+    dist.init_from_env(backend="gloo")          # both ranks share cuda:0 here; on a node it is nccl (RCCL), one GPU per rank
+    graph = rmat_graph(13, 150_000, seed=4, accel=None)
+    gen = torch.Generator().manual_seed(1)
+    table = torch.randn(graph.num_nodes, 64, generator=gen).to(DEV)
+    rowptr, col = graph.to(DEV)
+    torch.manual_seed(10 + rank)                # different initial weights per rank: the broadcast must make them equal
+    tr = EngineTrainer(rowptr, col, table, 4, hidden1=32, hidden2=16, num_sample1=5, num_sample2=5, gcn=True, max_batch=128)
+    rs = np.random.default_rng(0)
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    labels_all = torch.from_numpy(rs.integers(0, 4, graph.num_nodes)).to(DEV)
+    losses = []
+    for step in range(6):
+        batch = rs.choice(cand, 256, replace=False)               # same global batch on every rank (same generator state)
+        mine = dist.shard_batch(list(batch), rank, world)
+        ids = torch.as_tensor(np.asarray(mine, dtype=np.int32)).to(DEV)
+        losses.append(float(tr.step(ids, labels_all[ids.long()], key=1000 * rank + step, global_batch=len(batch))))
+    w = torch.cat([p.reshape(-1).cpu() for p in tr.parameters()])
+    torch.save({"w": w, "losses": losses}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_engine_trainer_data_parallel_one_flat_all_reduce_keeps_replicas_identical(tmp_path):
+    """seeds shard across ranks, graph / table / weights are replicated, ONE all-reduce of the weight gradients per
+    step.  Two ranks (gloo, sharing this box's GPU; RCCL on a node): started from different weights, they must be bit-identical
+    after the broadcast and stay so through six steps, each with its own sampler stream."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a["w"], b["w"]), "replicas diverged"
+    assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
