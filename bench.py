@@ -73,6 +73,8 @@ def parse():
                     help="untimed forwards on throw-away batches BEFORE the W warm-up steps, until this much time has passed: a GPU that "
                          "sat idle while the host built the inputs needs tens of ms of load to reach its sustained clocks (measured: the "
                          "first 250 forwards of a process run 20 %% slower than the next 250); 0 = none.  Declared in config.preheat")
+    ap.add_argument("--no-variant", action="store_true",
+                    help="skip the second timed run with the engine in the caller's node order (reported as config.variants)")
     ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "4")), help="pipe: batches in flight (workspaces)")
     ap.add_argument("--roles", default=os.environ.get("SAGE_ROLES", "SGDL"), help="pipe: roles S,G,D,L -> streams, e.g. SGDL, SGDD")
     ap.add_argument("--batches-per-replay", type=int, default=0,
@@ -493,13 +495,42 @@ def main():
             except Exception:
                 pass
 
+    # ---- variant, reported beside the headline and never substituted for it: the same K steps with the engine keeping the
+    #      CALLER's node order (no degree-sorted internal layout), same execution mode ----
+    variants = None
+    if rank == 0 and world == 1 and pipe is not None and relabel is not None and not args.no_variant:
+        role_streams = pipe.distinct_streams()       # the variant runs on the SAME role streams (hence hardware queues)
+        del pipe
+        torch.cuda.synchronize()
+        ekw_in = dict(ekw, relabel=None)
+        pipe_in = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, streams=role_streams, **ekw_in)
+        t_ph = time.perf_counter()
+        while time.perf_counter() - t_ph < min(args.preheat_seconds, 0.2):
+            pipe_in.submit_many(ph_seeds, ph_keys, pipe_out) if args.preheat_seconds > 0 else None
+            torch.cuda.synchronize()
+        for i in range(args.warmup):
+            pipe_in.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
+        torch.cuda.synchronize()
+        t0v = time.perf_counter()
+        for i in range(args.warmup, total_steps):
+            pipe_in.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
+        torch.cuda.synchronize()
+        el_v = time.perf_counter() - t0v
+        variants = {"engine_layout_input": {"value": round(b * args.steps / el_v, 1), "ms_per_step": round(el_v / args.steps * 1e3, 5),
+                                            "note": "engine keeps the caller's node order (TwoHopEngine(relabel=None)); same steps, same execution mode"}}
+        del pipe_in
+        pipe = None
+        was_pipe = True
+    else:
+        was_pipe = pipe is not None
+
     # ---- CPU side by side: the reference-faithful restatement on this box's host cores ----
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu_baseline = cpu_port_baseline(graph, table.cpu(), w1.cpu(), w2.cpu(), candidates, k1, k2, concat, args.cpu_seconds)
 
     if rank == 0:
-        if pipe is not None:
+        if was_pipe:
             execution = f"role pipeline {args.roles} (stages S/G/D/L on HIP streams, hipEvent hand-offs), {args.depth} batches in flight"
         elif exec_mode == "replay":
             execution = f"hipGraph replay from a device batch queue, {nstreams} forwards in flight"
@@ -519,6 +550,7 @@ def main():
                        "contraction": "bf16x3-split MFMA (fp32-accurate: x.w from the three bf16 terms of x and of w; weight planes prepared "
                                       "once per weight update by sage_prepare_weights)",
                        "batches_per_replay": bpr if exec_mode == "replay" else 1,
+                       "variants": variants,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
             "parity_max_err_vs_fp64_oracle": parity_err,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

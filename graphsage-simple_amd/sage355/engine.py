@@ -332,7 +332,7 @@ class RolePipeline:
     `priorities`: per distinct stream, 0 = default, -1 = high (HIP stream priority; the latency-bound roles).
     The reference has no counterpart (model.py:240-252 is one batch at a time on the host)."""
 
-    def __init__(self, rowptr, col, table, w1, w2, k1, k2, batch, depth=4, roles="SGDL", priorities=None, **engine_kwargs):
+    def __init__(self, rowptr, col, table, w1, w2, k1, k2, batch, depth=4, roles="SGDL", priorities=None, streams=None, **engine_kwargs):
         import ctypes
         if depth < 1 or depth > native.PIPE_MAX_DEPTH:
             raise native.SageError(f"RolePipeline: depth must be in [1, {native.PIPE_MAX_DEPTH}]")
@@ -346,7 +346,14 @@ class RolePipeline:
             if ch not in names:
                 names.append(ch)
         priorities = priorities or {}
-        self._streams = {ch: torch.cuda.Stream(device=self.device, priority=int(priorities.get(ch, 0))) for ch in names}
+        if streams is not None:
+            # reuse another pipe's role streams (e.g. a pipe that was just destroyed): which hardware queue a NEW HIP stream lands
+            # on is the runtime's choice, and two role streams on one queue serialise (82-93 us per forward instead of 66-74)
+            if len(streams) != len(names):
+                raise native.SageError(f"RolePipeline: {len(names)} distinct role streams needed, {len(streams)} given")
+            self._streams = dict(zip(names, streams))
+        else:
+            self._streams = {ch: torch.cuda.Stream(device=self.device, priority=int(priorities.get(ch, 0))) for ch in names}
         self.role_streams = [self._streams[ch] for ch in roles]
         ws = (ctypes.c_void_p * depth)(*[e.workspace.data_ptr() for e in self.engines])
         st = (ctypes.c_void_p * 4)(*[s.cuda_stream for s in self.role_streams])
@@ -378,6 +385,10 @@ class RolePipeline:
             except Exception:
                 pass
             self._h = None
+
+    def distinct_streams(self):
+        """The pipe's distinct role streams, in first-use order of `roles` (pass them to another pipe's `streams=`)."""
+        return list(self._streams.values())
 
     def fork(self, stream=None):
         """Every role stream waits for `stream` (default: the current one): inputs written there are ready."""
