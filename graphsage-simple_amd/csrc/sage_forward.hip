@@ -46,7 +46,7 @@ extern "C" int sage_forward2_layout(const sage_model_t* m, int32_t max_batch, sa
     const int64_t max_s1 = B * m->k2 + B;   // frontier of B*k2 ids + B self rows (concat or self-loop)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    L->counters = take(32 * sizeof(int32_t));    // 16 counters + the sampler key of a pipelined forward (sage_forward2_stages)
+    L->counters = take(32 * sizeof(int32_t));    // 16 counters + a spare 64-bit slot (sampler key of a stage-wise forward)
     L->hash_capacity = next_pow2(2 * B * (m->k2 + 1));
     L->hash_keys = take((size_t)L->hash_capacity * 4);
     L->hash_rows = take((size_t)L->hash_capacity * 4);

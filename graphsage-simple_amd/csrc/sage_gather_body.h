@@ -1,5 +1,4 @@
-// Column-sliced gather block body (shared by gather_mean_sliced_kernel, sage_gather.hip, and the fused gather + next-batch
-// outer sample launch, sage_pipeline.hip): expressed in (bid, nblk) instead of blockIdx / gridDim.
+// Column-sliced gather block bodies (the kernels of sage_gather.hip), expressed in (bid, nblk) instead of blockIdx / gridDim.
 #pragma once
 #include "sage_internal.h"
 
