@@ -32,7 +32,6 @@ struct sage_pipe {
     hipEvent_t ev[4][SAGE_PIPE_MAX_DEPTH];              // [role][slot]: role's work on the slot's batch is enqueued
     hipEvent_t ev_fork;
     uint64_t submitted;
-    bool split;                                         // layer 1 runs as gather + contraction (else one launch on D)
 };
 
 namespace {
@@ -86,7 +85,6 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     p->depth = depth;
     p->ws_bytes = workspace_bytes;
     p->submitted = 0;
-    p->split = L.layer1_split != 0;
     for (int i = 0; i < depth; ++i) p->ws[i] = workspaces[i];
     for (int r = 0; r < 4; ++r) p->st[r] = (hipStream_t)streams[r];
     for (int r = 0; r < 4; ++r)
@@ -126,9 +124,9 @@ extern "C" int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const f
     return SAGE_OK;
 }
 
-// One batch through the four role streams.  `first_in_segment`: no earlier submit of this pipe is outstanding on the
-// slot (a fresh pipe, or the first `depth` submits inside a stream capture, where the captured graph itself orders
-// replays): the workspace-release wait is skipped.
+// One batch through the four role streams.  `fresh_slot`: no earlier submit of this pipe is outstanding on the slot (a fresh
+// pipe, or the first `depth` submits after the caller joined and synchronised everything before): the workspace-release wait
+// is skipped.
 static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot,
                       void* const* gather_events = nullptr) {
     const int slot = (int)(p->submitted % (uint64_t)p->depth);
@@ -191,8 +189,7 @@ extern "C" int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64
     return SAGE_OK;
 }
 
-// Make `stream` wait for everything submitted so far (all four roles).  Also the join a stream capture needs before
-// it ends: the role streams forked from the capturing stream through the events above.
+// Make `stream` wait for everything submitted so far (all four roles).
 extern "C" int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream) {
     SAGE_REQUIRE(p, "pipe_join: NULL pipe");
     if (p->submitted == 0) return SAGE_OK;
@@ -212,7 +209,7 @@ extern "C" int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream) {
     return SAGE_OK;
 }
 
-// Fork: make every role stream wait for `stream` (the start of a captured segment, or "inputs are ready").
+// Fork: make every role stream wait for `stream` ("the inputs written there are ready").
 extern "C" int sage_pipe_fork(sage_pipe_t* p, sage_stream_t stream) {
     SAGE_REQUIRE(p, "pipe_fork: NULL pipe");
     hipStream_t st = (hipStream_t)stream;
