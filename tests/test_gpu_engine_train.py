@@ -52,14 +52,15 @@ def _autograd_reference(tr, seeds, labels):
     return loss.item(), g
 
 
+@pytest.mark.parametrize("relabel", [None, "degree"])
 @pytest.mark.parametrize("gcn,d0,h1", [(True, 256, 128), (False, 100, 52), (True, 1433, 50), (False, 66, 30)])
-def test_engine_gradients_match_fp64_autograd_on_the_same_sets(gcn, d0, h1):
+def test_engine_gradients_match_fp64_autograd_on_the_same_sets(gcn, d0, h1, relabel):
     graph = rmat_graph(13, 150_000, seed=4, accel=None)
     gen = torch.Generator().manual_seed(1)
     table = torch.randn(graph.num_nodes, d0, generator=gen).to(DEV)
     rowptr, col = graph.to(DEV)
     torch.manual_seed(3)
-    tr = EngineTrainer(rowptr, col, table, 5, hidden1=h1, hidden2=64, num_sample1=7, num_sample2=9, gcn=gcn, max_batch=300)
+    tr = EngineTrainer(rowptr, col, table, 5, hidden1=h1, hidden2=64, num_sample1=7, num_sample2=9, gcn=gcn, max_batch=300, relabel=relabel)
     seeds = np.random.default_rng(2).choice(np.nonzero(graph.degrees() > 0)[0], 300, replace=False)
     labels = torch.from_numpy(np.random.default_rng(3).integers(0, 5, 300)).to(DEV)
     loss, grads = tr.grads(torch.from_numpy(seeds.astype(np.int32)).to(DEV), labels, key=11)

@@ -400,3 +400,22 @@ torch.save(dict(out=out.cpu(), nbr2=it["nbr2"].cpu(), cnt2=it["cnt2"].cpu(), s1=
     assert torch.equal(a["nbr2"], b["nbr2"]) and torch.equal(a["cnt2"], b["cnt2"]) and torch.equal(a["s1"], b["s1"])
     assert a["rows_ok"] and b["rows_ok"]
     assert _eq(a["out"], b["out"])
+
+
+def test_graph_replay_from_a_batch_queue_with_the_degree_layout():
+    """Device batch queue + hipGraph replay (sage_model_t.queue) with the engine's internal degree layout: the queued seeds are in
+    the caller's ids and the outer-hop kernel translates them (model.seed_map) -- replays equal direct forwards bit for bit."""
+    graph, table, w1, w2 = _problem()
+    rp, cl = graph.to(DEV)
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    rs = np.random.default_rng(4)
+    seeds = torch.from_numpy(np.stack([rs.choice(cand, 512, replace=False) for _ in range(5)]).astype(np.int32)).to(DEV)
+    keys = [31, 32, 33, 34, 35]
+    eng = TwoHopEngine(rp, cl, table.to(DEV), w1.to(DEV), w2.to(DEV), 10, 20, max_batch=512, relabel="degree")
+    want = [eng.forward(seeds[i], seed=keys[i]).clone() for i in range(5)]
+    eng.set_queue(seeds, keys)
+    out = eng.capture()
+    for i in range(5):
+        eng.replay()
+        torch.cuda.synchronize()
+        assert _eq(out, want[i]), f"replay {i}"
