@@ -347,6 +347,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     run(range(args.warmup, total_steps))
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # how long the host needed per step (it must stay below ms_per_step)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -542,7 +543,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
-                       "execution": execution, "fused_layers": not args.unfused,
+                       "execution": execution, "host_enqueue_ms_per_step": round(host_enqueue_ms, 5), "fused_layers": not args.unfused,
                        "preheat": f"{preheat_forwards} untimed forwards on throw-away batches before the {args.warmup} warm-up steps (GPU clock ramp)",
                        "node_order": args.node_order if args.config != 2 else "original",
                        "engine_layout": (relabel or "input") + (" (internal: rows by descending degree; seeds arrive in the generator's ids and are "
