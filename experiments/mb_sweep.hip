@@ -1,0 +1,143 @@
+// experiment: SWEEP gather.  Every lane group (16 lanes = one 256-B column slice) owns a few destination rows for the
+// whole launch, sorts ITS edges by source-id bucket (P buckets of equal edge mass, ascending id) into an LDS list, and
+// then walks that list: a pure stream of independent row loads, partial sums parked in LDS.  All groups of an XCD walk
+// the id space in the same direction at the same pace, so a source row that several destinations of the XCD share is
+// fetched while it is still in that XCD's L2 (experiments/l2_sweep_sim.py: misses 148 -> 115 MB).  Not product code.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int SL = 16;
+constexpr int NB = 8;                                            // buckets
+
+struct Bounds { int32_t t[NB - 1]; };
+
+__device__ __forceinline__ uint32_t row_scan_incl(uint32_t x) {  // inclusive scan over the 16 lanes of a DPP row
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    return x;
+}
+__device__ __forceinline__ uint32_t field(uint32_t lo, uint32_t hi, int b) { return ((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu; }
+
+template <int RG, int T, int THREADS>
+__global__ __launch_bounds__(THREADS) void gm_sweep(const float* __restrict__ table, int64_t ld, const int32_t* __restrict__ nbr,
+    const int32_t* __restrict__ cnt, int k, int n, Bounds bd, float* __restrict__ out, int64_t ldo, int nslice) {
+    extern __shared__ char smem[];
+    constexpr int GPB = THREADS / SL;                            // lane groups per block
+    f4* acc = reinterpret_cast<f4*>(smem);                        // [RG][GPB][SL]
+    uint32_t* list = reinterpret_cast<uint32_t*>(smem + (size_t)RG * GPB * SL * 16);   // [GPB][RG * 16]
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (SL - 1);
+    const int g = threadIdx.x / SL;
+    const int slice = blockIdx.x % nslice, bq = blockIdx.x / nslice, nbq = gridDim.x / nslice;
+    const int G = nbq * GPB, gi = bq * GPB + g;
+    const int c0 = slice * SL * 4 + gl * 4;
+    const float* __restrict__ tcol = table + c0;
+    uint32_t* mylist = list + g * (RG * 16);
+    for (int base = 0; base < n; base += G * RG) {
+        uint32_t ent[RG];
+        int bk[RG], rk[RG], cj[RG], idj[RG];
+        uint32_t tlo = 0, thi = 0;                                // edges so far per bucket (8-bit fields)
+        // one round trip: counts and ids of all RG rows are requested unconditionally (clamped addresses), no branch
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            const int r = base + j * G + gi;
+            const int rq = min(r, n - 1);
+            cj[j] = cnt[rq];
+            idj[j] = nbr[(int64_t)rq * k + min(gl, k - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            const int r = base + j * G + gi;
+            const int c = r < n ? min(cj[j], k) : 0;
+            cj[j] = c;
+            const bool valid = gl < c;
+            const int id = valid ? idj[j] : 0;
+            int b = 0;
+#pragma unroll
+            for (int p = 0; p < NB - 1; ++p) b += id >= bd.t[p] ? 1 : 0;
+            bk[j] = b;
+            const uint32_t olo = (valid && b < 4) ? 1u << (8 * b) : 0u, ohi = (valid && b >= 4) ? 1u << (8 * (b - 4)) : 0u;
+            const uint32_t ilo = row_scan_incl(olo), ihi = row_scan_incl(ohi);
+            rk[j] = (int)field(tlo + ilo - olo, thi + ihi - ohi, b);     // rank inside its bucket, canonical (row, position) order
+            tlo += __shfl(ilo, 15, SL);
+            thi += __shfl(ihi, 15, SL);
+            ent[j] = (uint32_t)id | ((uint32_t)j << 28);
+        }
+        // bucket starts = exclusive prefix over the 8 fields
+        uint64_t x = ((uint64_t)thi << 32) | tlo;
+        x += x << 8; x += x << 16; x += x << 32;                  // inclusive
+        const int len = (int)(x >> 56);
+        const uint64_t st = x << 8;
+        const uint32_t slo = (uint32_t)st, shi = (uint32_t)(st >> 32);
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            if (gl < cj[j]) mylist[field(slo, shi, bk[j]) + rk[j]] = ent[j];
+            acc[(j * GPB + g) * SL + gl] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                         max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        for (int e0 = 0; e0 < maxlen; e0 += T) {
+            uint32_t en[T];
+            f4 t[T];
+#pragma unroll
+            for (int u = 0; u < T; ++u) en[u] = mylist[min(e0 + u, RG * 16 - 1)];
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                if (e0 + u < len) t[u] = *reinterpret_cast<const f4*>(tcol + (int64_t)(en[u] & 0x0fffffffu) * ld);
+                else t[u] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                if (e0 + u < len) {
+                    const int idx = ((int)(en[u] >> 28) * GPB + g) * SL + gl;
+                    f4 a = acc[idx];
+                    a += t[u];
+                    acc[idx] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            const int r = base + j * G + gi;
+            if (r < n) {
+                const f4 a = acc[(j * GPB + g) * SL + gl];
+                const f4 res = cj[j] > 0 ? a * (1.0f / (float)cj[j]) : f4{0.f, 0.f, 0.f, 0.f};
+                __builtin_nontemporal_store(res, reinterpret_cast<f4*>(out + (int64_t)r * ldo + c0));
+            }
+        }
+    }
+}
+
+template <int RG, int T, int THREADS>
+static int launch(int blocks, const float* table, int64_t ld, const int32_t* nbr, const int32_t* cnt, int k, int n, const Bounds& bd,
+                  float* out, int64_t ldo, int nslice, hipStream_t st) {
+    constexpr int GPB = THREADS / SL;
+    const size_t lds = (size_t)RG * GPB * SL * 16 + (size_t)GPB * RG * 16 * 4;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gm_sweep<RG, T, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        once = true;
+    }
+    hipLaunchKernelGGL((gm_sweep<RG, T, THREADS>), dim3(blocks), dim3(THREADS), lds, st, table, ld, nbr, cnt, k, n, bd, out, ldo, nslice);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// mode: 0 = 1024 threads RG 7 T 8 (1 block per CU); 1 = 512 threads RG 7 T 8 (2 per CU); 2 = 1024 threads T 4; 3 = 512 threads T 4
+extern "C" int run_sweep(int mode, int blocks, const float* table, int64_t ld, const int32_t* nbr, const int32_t* cnt, int k, int n,
+                         const int32_t* bounds, float* out, int64_t ldo, hipStream_t st) {
+    if (k > 16) return -3;
+    Bounds bd;
+    for (int i = 0; i < NB - 1; ++i) bd.t[i] = bounds[i];
+    switch (mode) {
+    case 0: return launch<7, 8, 1024>(blocks, table, ld, nbr, cnt, k, n, bd, out, ldo, 4, st);
+    case 1: return launch<7, 8, 512>(blocks, table, ld, nbr, cnt, k, n, bd, out, ldo, 4, st);
+    case 2: return launch<7, 4, 1024>(blocks, table, ld, nbr, cnt, k, n, bd, out, ldo, 4, st);
+    case 3: return launch<7, 4, 512>(blocks, table, ld, nbr, cnt, k, n, bd, out, ldo, 4, st);
+    case 4: return launch<4, 8, 512>(blocks, table, ld, nbr, cnt, k, n, bd, out, ldo, 4, st);
+    case 5: return launch<7, 16, 512>(blocks, table, ld, nbr, cnt, k, n, bd, out, ldo, 4, st);
+    }
+    return -4;
+}

@@ -30,7 +30,7 @@ const sage_tunables_t& sage_tunables() {
     static const sage_tunables_t t = [] {
         sage_tunables_t x;
         x.gather_blocks_per_cu = env_int("SAGE_G_PER_CU", 6, 1, 8);
-        { const int sl = env_int("SAGE_G_SLICE_LANES", 0, 0, 32); x.gather_slice_lanes = (sl == 8 || sl == 16 || sl == 32) ? sl : 0; }
+        { const int sl = env_int("SAGE_G_SLICE_LANES", 0, 0, 64); x.gather_slice_lanes = (sl == 8 || sl == 16 || sl == 32 || sl == 64) ? sl : 0; }
         x.gather_rows_in_flight = env_int("SAGE_G_ROWS", 1, 1, 4);
         x.gather_trip = env_int("SAGE_G_TRIP", 16, 8, 16) >= 16 ? 16 : 8;
         x.gather_variant = env_int("SAGE_G_VARIANT", 1, 0, 2);

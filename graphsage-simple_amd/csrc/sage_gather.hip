@@ -165,7 +165,8 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
 #else
         constexpr bool kForce = false;
         const int forced = sage_tunables().gather_slice_lanes;
-        const int sl = forced ? forced : ((dim <= 128 && dim % 64 != 0) ? 32 : 16);
+        int sl = forced ? forced : ((dim <= 128 && dim % 64 != 0) ? 32 : 16);
+        if (sl == 64 && sage_tunables().gather_variant != 1) sl = 16;      // whole-row slices exist in the pipelined form only
 #endif
         (void)kForce;
         const int nslice = sage_cdiv(dim, sl * 4);
@@ -182,7 +183,10 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
             // rows software-pipelined: every neighbour of a row in ONE trip (U wave-instructions of 64/sl neighbours), the
             // next row's ids requested meanwhile.  U by fanout; lists longer than U x 64/sl take further trips.
             const int per = kWave / sl, need = sage_cdiv(k, per);
-            if (sl == 8) {
+            if (sl == 64) {     // whole 1-KiB rows, one neighbour per wave-instruction: graphs with little reuse (every row read once)
+                if (need <= 8) launch_pipe<64, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+                else launch_pipe<64, 16>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
+            } else if (sl == 8) {
                 if (need <= 2) launch_pipe<8, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
                 else if (need <= 4) launch_pipe<8, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);
                 else launch_pipe<8, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);

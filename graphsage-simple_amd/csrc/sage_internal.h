@@ -75,7 +75,7 @@ int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t w
 // measured optima recorded in DESIGN.md).  Every value is clamped to a safe range.
 struct sage_tunables_t {
     int gather_blocks_per_cu;     // SAGE_G_PER_CU        sliced gather: 256-thread blocks per CU (1..8), default 6
-    int gather_slice_lanes;       // SAGE_G_SLICE_LANES   0 = by row width (16 lanes = 256-B slices; 32 for narrow odd rows), or 8 / 16 / 32
+    int gather_slice_lanes;       // SAGE_G_SLICE_LANES   0 = by row width (16 lanes = 256-B slices; 32 for narrow odd rows), or 8 / 16 / 32 / 64 (64: variant 1 only)
     int gather_rows_in_flight;    // SAGE_G_ROWS          pipelined gather: rows of a wave in flight together (1 / 2 / 4), default 1
     int gather_trip;              // SAGE_G_TRIP          rows form: neighbours of a row requested per trip (8 / 16), default 16
     int gather_variant;           // SAGE_G_VARIANT       0 = three-trip rows, 1 = rows software-pipelined (default), 2 = one row per lane group

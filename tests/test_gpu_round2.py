@@ -176,6 +176,8 @@ VARIANTS = [
     {"SAGE_G_VARIANT": "2", "SAGE_G_TRIP": "8", "SAGE_G_PER_CU": "2"},
     {"SAGE_G_VARIANT": "2", "SAGE_G_TRIP": "16", "SAGE_G_SLICE_LANES": "8", "SAGE_G_PER_CU": "3"},
     {"SAGE_G_VARIANT": "2", "SAGE_G_SLICE_LANES": "32"},
+    {"SAGE_G_VARIANT": "1", "SAGE_G_SLICE_LANES": "64"},
+    {"SAGE_G_VARIANT": "2", "SAGE_G_SLICE_LANES": "64"},
     {"SAGE_DENSE_BLOCKS": "512", "SAGE_T16_WAVES": "8", "SAGE_SO_THREADS": "256"},
     {"SAGE_DENSE_BLOCKS": "96", "SAGE_SO_THREADS": "512", "SAGE_T16_GRID": "128"},
     {"SAGE_SAMPLE_FUSED": "1", "SAGE_T16_WAVES": "16"},
