@@ -225,6 +225,12 @@ __device__ inline void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo
     lo = __builtin_convertvector(r2, bf16x4);
 }
 
+// Block barrier for data exchanged through LDS only.  __syncthreads() carries a workgroup-scope fence, and on gfx9 a release
+// fence is `s_waitcnt vmcnt(0)`: it DRAINS every global load in flight -- the W slice (24 KiB per wave) requested in the
+// prologue, the next tile's rows requested before the MFMA loop -- at each of the two barriers per tile.  Here only the LDS
+// queue is waited for; the compiler still waits for a load where its value is used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // out[g][col] before the activation as an fp32 fma chain over k (the [self | agg] order of encoders.py:54): the slow, exact
 // form for tiles that hold |x| >= 2^127 / Inf / NaN (never taken on ordinary data: one LDS word per tile decides)
 __device__ inline float exact_row_dot(const DenseArgs& a, bool concat, int g, int col, bool nan_rule) {
@@ -256,7 +262,9 @@ __device__ inline bool row_is_huge(const DenseArgs& a, bool concat, int g, bool 
 }
 
 // MP (KP = 256 only): rows wider than 256 -- every K chunk takes ceil(dim / 256) passes (Pubmed 500, Cora 1433+3 pad).
-template <int KP, bool CONCAT, bool MP>
+// PREP: W arrives as the planes of sage_prepare_weights (a.wsplit; one-pass shapes only) -- a compile-time property, so that no
+// join of two W paths stands between the W loads and their first use.
+template <int KP, bool CONCAT, bool MP, bool PREP = false>
 __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     constexpr int M = 32, WAVES = 8;
     constexpr int CHUNKS = CONCAT ? 2 : 1;
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     static_assert(!MP || KP == 256, "multi-pass rows use 256-wide passes");
     constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1;    // K chunks staged per pass
     constexpr bool MULTI = MP || (CONCAT && KP == 256);  // more than one pass: group accumulators
+    static_assert(!PREP || !MULTI, "prepared planes exist for the one-pass shapes");
     constexpr int KPASS = PCH * KP;                      // K columns per pass (<= 256)
     constexpr int KH = KPASS / 2, STEPS = KH / 16;
     constexpr int TG = MP ? SAGE_MP_TG : (MULTI ? 4 : 1);
@@ -300,20 +309,25 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const int npass = (CHUNKS / PCH) * ppc;
 
         f32x4 xr[PCH][PASSES];
-        auto request_tile = [&](int tile, int pass) {        // global -> VGPRs, no wait
+        int xc[PASSES];                                       // neighbour counts of the requested rows (0/0 rule only)
+        // global -> VGPRs, no wait.  No lane-dependent branch anywhere near these loads: rows past the end and columns past
+        // the row width are requested from clamped addresses and masked when the tile is staged.  (`x = 0; if (valid) x = load`
+        // compiles to a divergent branch whose join COPIES the loaded registers -- a use, so the compiler waited for the loads
+        // right where they were issued and nothing was in flight during the MFMA loop.)
+        auto request_tile = [&](int tile, int pass) {
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc) {
-                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean
-                const int coff = (pass % ppc) * KP + c0;                         // this lane's first column of the chunk
+                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean (block-uniform)
+                const int coff = min((pass % ppc) * KP + c0, a.dim - 4);         // this lane's first column of the chunk (dim % 4 == 0)
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
-                    const int g = tile * M + wave * RPW + p * RPP + sg;
-                    const bool valid = g < nn && coff < a.dim;
-                    xr[pc][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (valid && is_agg) {
-                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff);
-                        if (nan_rule && a.cnt[g] == 0) { const float q = __builtin_nanf(""); xr[pc][p] = f32x4{q, q, q, q}; }
-                    } else if (valid) {
+                    const int g = min(tile * M + wave * RPW + p * RPP + sg, nn - 1);
+                    if (is_agg) {
+                        // streaming load: every row of the means is read once, and left in L2 it would evict the gather's hub rows
+                        // of the NEXT batch, which runs beside this kernel (same-box A/B with the sampler's nt loads: -0.8 us per forward)
+                        xr[pc][p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff));
+                        if (nan_rule) xc[p] = a.cnt[g];
+                    } else {
                         const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1)
                                                        : (int64_t)min(g, a.self_rows - 1);
                         xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + coff);
@@ -323,8 +337,21 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         };
         int stage_seq = 0;                                    // stagings so far (block-uniform): the tag a "huge value" mark carries,
                                                               // so that marks never have to be cleared (a clear would race the next staging)
-        auto stage_tile = [&](__bf16* buf, int bsel) {        // VGPRs -> split -> three bf16 LDS planes
+        auto stage_tile = [&](__bf16* buf, int bsel, int tile, int pass) {   // VGPRs -> mask -> split -> three bf16 LDS planes
             ++stage_seq;
+#pragma unroll
+            for (int pc = 0; pc < PCH; ++pc) {
+                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;
+                const bool col_ok = (pass % ppc) * KP + c0 < a.dim;
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const bool valid = col_ok && tile * M + wave * RPW + p * RPP + sg < nn;
+                    const bool nanrow = nan_rule && is_agg && xc[p] == 0;         // aggregators.py:60-61 (0/0 rows of a batch that has non-empty ones)
+                    const float q = __builtin_nanf("");
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[pc][p][e] = valid ? (nanrow ? q : xr[pc][p][e]) : 0.f;
+                }
+            }
             bool huge = false;
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc)
@@ -350,7 +377,9 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         };
 
         if (tid < 96) flags[tid] = 0;                         // ordered before the first staging by the barrier below
-        __syncthreads();
+        lds_barrier();
+        if constexpr (PREP)                                   // sage_prepare_weights left "W holds |w| >= 2^127 / Inf / NaN" behind the planes
+            if (tid == 0 && a.wsplit[(size_t)WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
         STAMP(0);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
@@ -362,8 +391,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         const float* wrow = a.W + (int64_t)min(n0 + i32, a.out_dim - 1) * a.ldw;
         bf16x8 bw[STEPS][3];
         auto load_w = [&](int pass) {
-            if constexpr (!MULTI) {
-                if (a.wsplit) {
+            if constexpr (PREP) {
+                {
                     // planes prepared by sage_prepare_weights: [wave][step][plane][lane] x 16 B, so every load is one
                     // fully coalesced 1-KiB wave-instruction and nothing is split here (the strided fp32 loads + 16 split3
                     // per lane below took 8000 cycles per wave and ~15000 until the block's slowest wave had its slice:
@@ -374,14 +403,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
                             const uint4 v = wp[(st * 3 + pl) * 64];
-                            bw[st][pl] = __builtin_bit_cast(bf16x8, v);
-                            if (pl == 0) {                    // first-term plane: bf16 exponent field 254 / 255 <=> the fp32 value was huge
-                                const bool hg = ((v.x & 0x7F80u) >= 0x7F00u) | ((v.x & 0x7F800000u) >= 0x7F000000u) | ((v.y & 0x7F80u) >= 0x7F00u) |
-                                                ((v.y & 0x7F800000u) >= 0x7F000000u) | ((v.z & 0x7F80u) >= 0x7F00u) | ((v.z & 0x7F800000u) >= 0x7F000000u) |
-                                                ((v.w & 0x7F80u) >= 0x7F00u) | ((v.w & 0x7F800000u) >= 0x7F000000u);
-                                if (__any(hg) && lane == 0) flags[2] = 1;
-                            }
-                        }
+                            bw[st][pl] = __builtin_bit_cast(bf16x8, v);   // no use of v here: the loads stay in flight (the "W holds a
+                        }                                                 // huge value" mark comes from the buffer's trailer, see below)
                     return;
                 }
             }
@@ -407,7 +430,11 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         (void)stamp_i;
 
         int b = 0;
-        for (int t0 = (int)blockIdx.x; t0 < ntiles; t0 += TG * stride) {
+        // One group of up to TG tiles.  Called once ahead of the loop (the block's first group, straight-line code) and then from
+        // the loop: at a loop header the compiler waits for EVERY load in flight (s_waitcnt vmcnt(0)), which in the first
+        // iteration meant the whole W slice; peeled, the first tile is staged while W travels (only its own rows are waited
+        // for: they were requested first) and its MFMA steps start as their W registers arrive.
+        auto do_group = [&](const int t0) __attribute__((always_inline)) {
             f32x16 acc[TG];
             int bad[TG];                                      // block-uniform: some value of tile t (any pass) or of W is huge
 #pragma unroll
@@ -429,8 +456,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     const int tile = t0 + t * stride;
                     if (tile >= ntiles) continue;             // block-uniform
                     __bf16* buf = lds + b * 3 * PL;
-                    stage_tile(buf, b);
-                    __syncthreads();
+                    stage_tile(buf, b, tile, pass);
+                    lds_barrier();
                     {   // bit 0: the tile (goes on the redo list); bits 1, 2: the two rows THIS thread stores in the epilogue; bit 3: W
                         const int re = wave * (M / WAVES) + (lane >> 5);
                         bad[t] |= (flags[b] == stage_seq ? 1 : 0) | (flags[32 + 32 * b + re] == stage_seq ? 2 : 0) |
@@ -475,13 +502,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
             for (int t = 0; t < TG; ++t) {
                 const int tile = t0 + t * stride;
                 if (tile >= ntiles) continue;
-                if (TG > 1 && t > 0) __syncthreads();         // the previous tile's partial sums have been read
+                if (TG > 1 && t > 0) lds_barrier();           // the previous tile's partial sums have been read
                 if (mfma_wave) {
                     float* mine = part + (size_t)kgroup * M * PLD + n0 + i32;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) mine[((reg & 3) + 8 * (reg >> 2) + 4 * h) * PLD] = acc[t][reg];
                 }
-                __syncthreads();
+                lds_barrier();
                 if (tid == 0 && (bad[t] & 1)) { const int i = flags[3]++; if (i < kBadListCap) flags[4 + i] = tile; }   // only thread 0 touches these
 #pragma unroll
                 for (int it = 0; it < M / (WAVES * 2); ++it) {
@@ -508,11 +535,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 }
                 STAMP(stamp_i); ++stamp_i;
             }
-        }
+        };
+        do_group((int)blockIdx.x);
+        for (int t0 = (int)blockIdx.x + TG * stride; t0 < ntiles; t0 += TG * stride) do_group(t0);
         STAMP(39);
         // Tiles that held |x| >= 2^127 / Inf / NaN (or all tiles, when W does): the exact fp32 fma chain, outside the loop above
         // so that it costs the ordinary path no register.  Block-uniform; zero iterations on ordinary data.
-        __syncthreads();
+        lds_barrier();
         const int nbad = flags[3];
         if (nbad > 0) {
             const bool all = nbad > kBadListCap || flags[2] != 0;
@@ -530,13 +559,15 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-template <int KP, bool CONCAT, bool MP = false>
+template <int KP, bool CONCAT, bool MP = false, bool PREP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
+    if constexpr (!CONCAT && !MP && !PREP)
+        if (a.wsplit) return launch_bf16x3<KP, CONCAT, MP, true>(a, st);
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
     static bool configured = false;
     if (!configured) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP, PREP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess) {
             sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
@@ -548,7 +579,7 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     // and the other batch's latency-bound kernels get the remaining CUs to themselves (same-box A/B: 184-224 blocks
     // 81.3-81.9 us, 256 blocks 84.2, 160 blocks 83.1).
     const int grid = min(sage_cdiv(a.n, 32), sage_tunables().dense_blocks);
-    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP>), dim3(grid), dim3(512), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
     return SAGE_OK;
 }
@@ -561,6 +592,7 @@ __global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw,
     constexpr int KH = KP / 2, STEPS = KH / 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 8 * STEPS * 64) return;
+    uint4* trailer = prepared + (size_t)8 * STEPS * 3 * 64;   // .x != 0: W holds |w| >= 2^127 / Inf / NaN (zeroed by the launcher)
     const int lane = idx & 63, st = (idx >> 6) % STEPS, wave = idx / (64 * STEPS);
     const int row = 32 * (wave & 3) + (lane & 31);
     const int kk = (wave >> 2) * KH + 16 * st + 8 * (lane >> 5);
@@ -572,6 +604,7 @@ __global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw,
             if (kk + 4 + e < dim) v1[e] = W[(int64_t)row * ldw + kk + 4 + e];
         }
     }
+    if (huge4(v0) || huge4(v1)) atomicOr(&trailer->x, 1u);
     bf16x4 h0, m0, l0, h1, m1, l1;
     split3(v0, h0, m0, l0);
     split3(v1, h1, m1, l1);
@@ -594,7 +627,7 @@ int prepared_kp(int32_t dim, int32_t out_dim) {
 // Prepared weights exist for the non-concat contraction with dim <= 256 (the one-pass kernel); 0 = this layer shape takes W as it is.
 extern "C" size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat) {
     const int kp = concat ? 0 : prepared_kp(dim, out_dim);
-    return kp ? (size_t)8 * (kp / 32) * 3 * 64 * 16 : 0;
+    return kp ? (size_t)8 * (kp / 32) * 3 * 64 * 16 + 16 : 0;      // the planes + a 16-byte trailer (huge-value mark)
 }
 
 extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t out_dim, int32_t concat, void* prepared,
@@ -610,6 +643,7 @@ extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t di
     const int kp = prepared_kp(dim, out_dim);
     const int threads = 8 * (kp / 32) * 64, blocks = sage_cdiv(threads, 256);
     hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync((char*)prepared + need - 16, 0, 16, st) != hipSuccess) { sage_set_error("prepare_weights: hipMemsetAsync failed"); return SAGE_ELAUNCH; }
     if (kp == 64) hipLaunchKernelGGL(prepare_weights_kernel<64>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
     else if (kp == 128) hipLaunchKernelGGL(prepare_weights_kernel<128>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
     else hipLaunchKernelGGL(prepare_weights_kernel<256>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);

@@ -135,23 +135,31 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
     if (!fresh_slot)
         if (int rc = wait_on(p, RS, RL, slot)) return rc;
+#ifndef SAGE_PIPE_SKIP_S
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0,
                                              SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
         return rc;
+#endif
     if (int rc = record(p, RS, slot, p->st[RG] != p->st[RS])) return rc;
     // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
     if (int rc = wait_on(p, RG, RS, slot)) return rc;
     if (gather_events && gather_events[0] && hipEventRecord((hipEvent_t)gather_events[0], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
+#ifndef SAGE_PIPE_SKIP_G   // diagnostic builds (experiments/ab_build.sh): the pipeline without one of its stages' kernels, stale data downstream
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG])) return rc;
+#endif
     if (gather_events && gather_events[1] && hipEventRecord((hipEvent_t)gather_events[1], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
     if (int rc = record(p, RG, slot, p->st[RD] != p->st[RG])) return rc;
     // D: the contraction (or the whole fused layer 1)
     if (int rc = wait_on(p, RD, RG, slot)) return rc;
+#ifndef SAGE_PIPE_SKIP_D
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
+#endif
     if (int rc = record(p, RD, slot, p->st[RL] != p->st[RD])) return rc;
     // L: layer 2; afterwards the workspace is clean again
     if (int rc = wait_on(p, RL, RD, slot)) return rc;
+#ifndef SAGE_PIPE_SKIP_L
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, out, ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
+#endif
     if (int rc = record(p, RL, slot, p->st[RS] != p->st[RL])) return rc;
     ++p->submitted;
     return SAGE_OK;

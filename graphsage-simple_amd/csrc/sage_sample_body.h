@@ -137,7 +137,7 @@ __device__ __forceinline__ void sample_block(
         const bool floyd = active && deg > (int64_t)k;
         const uint32_t pos = sage_group_positions<G>(floyd, deg, k, v, (r < tag_self_rows) ? tag_self : tag, key0, key1, gl, lane);
         if (active) {
-            if (gl < c) id = col[s + (int64_t)pos];
+            if (gl < c) id = __builtin_nontemporal_load(col + s + (int64_t)pos);   // one 4-byte read per drawn position: streaming
             if (gl < k) nbr[(int64_t)r * k + gl] = id;
             if (gl == 0) cnt[r] = c;
         }
@@ -247,7 +247,7 @@ __device__ __forceinline__ void sample_inner_items(
         const bool floyd = active && deg > (int64_t)k;
         const uint32_t pos = sage_group_positions<G1>(floyd, deg, k, v, tag, key0, key1, gl, lane);
         if (active) {
-            if (gl < c) id = col[s + (int64_t)pos];
+            if (gl < c) id = __builtin_nontemporal_load(col + s + (int64_t)pos);   // one 4-byte read per drawn position: streaming
             if (gl < k) nbr[(int64_t)row * k + gl] = id;
             if (gl == 0) cnt[row] = c;
         }
