@@ -77,9 +77,16 @@ __global__ __launch_bounds__(THREADS) void gm_sweep(const float* __restrict__ ta
             if (gl < cj[j]) mylist[field(slo, shi, bk[j]) + rk[j]] = ent[j];
             acc[(j * GPB + g) * SL + gl] = f4{0.f, 0.f, 0.f, 0.f};
         }
+#ifdef SWEEP_LOCKSTEP   // all waves of the block walk position by position (block-uniform trip count, one barrier per trip)
+        const int maxlen = RG * k;
+#else
         int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
                          max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+#endif
         for (int e0 = 0; e0 < maxlen; e0 += T) {
+#ifdef SWEEP_LOCKSTEP
+            __builtin_amdgcn_s_barrier();
+#endif
             uint32_t en[T];
             f4 t[T];
 #pragma unroll

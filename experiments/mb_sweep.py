@@ -6,7 +6,7 @@ import numpy as np, torch
 from sage355 import ops
 from sage355.engine import TwoHopEngine
 from sage355.graph import rmat_graph
-lib = ctypes.CDLL(os.path.join(HERE, "mb_sweep.so"))
+lib = ctypes.CDLL(os.path.join(HERE, os.environ.get("MB_LIB", "mb_sweep.so")))
 dev = "cuda"
 NB = 8
 scale, edges = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (20, 16_000_000)
