@@ -40,7 +40,8 @@ for f in ("bench.json", "bench_under_rocprof.json", "bench_20_5.json", "bench_la
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(here, f"{tag}_{f}"))
 
-stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True))
+# gpurun merges a call's outputs INTO gpurun_out/ (nothing is deleted there): of several runs' files take the newest one only
+stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if stats:
     rows = list(csv.DictReader(open(stats[-1])))
     rows.sort(key=lambda r: (short(r["Name"]) is None, -float(r["TotalDurationNs"])))
@@ -56,7 +57,12 @@ if stats:
 def per_kernel(pattern):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
+    by_dir = {}
     for f in glob.glob(os.path.join(src, pattern, "**", "*_counter_collection.csv"), recursive=True):
+        d_ = os.path.dirname(f)                      # one pass = one directory: the newest file of each (older ones are earlier collections)
+        if d_ not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d_]):
+            by_dir[d_] = f
+    for f in by_dir.values():
         seen = set()
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
