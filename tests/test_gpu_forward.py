@@ -232,6 +232,23 @@ def test_two_hop_odd_batches_and_fanouts(b, k1, k2, concat):
     check_engine_against_oracle(graph, table, w1, w2, seeds, k1, k2, concat, False, True, seed=5)
 
 
+@pytest.mark.parametrize("concat,self_loop", [(False, False), (True, False), (False, True)])
+def test_two_hop_batch_with_repeated_seeds(concat, self_loop):
+    """A node may appear more than once in a batch (encoders.py:47 builds one neighbour list per POSITION of `nodes`): every
+    occurrence gets its own row of the output, the frontier still holds each node once, and the whole forward matches the
+    oracle on the sets the device sampled."""
+    graph = rmat_graph(13, 150_000, seed=4)
+    gen = torch.Generator().manual_seed(9)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, 128, generator=gen)
+    w1 = torch.randn(64, m * 128, generator=gen) / np.sqrt(m * 128)
+    w2 = torch.randn(32, m * 64, generator=gen) / np.sqrt(m * 64)
+    base = np.random.default_rng(3).choice(np.nonzero(graph.degrees() > 0)[0], 60, replace=False)
+    seeds = np.concatenate([base, base[:25], base[:5], base[:5]])        # 95 positions, 60 distinct nodes
+    np.random.default_rng(4).shuffle(seeds)
+    check_engine_against_oracle(graph, table, w1, w2, seeds, 7, 9, concat, self_loop, True, seed=6)
+
+
 @pytest.mark.parametrize("concat,self_loop", [(False, False), (True, True)])
 def test_relabel_by_degree_is_the_same_engine_on_the_renumbered_graph(concat, self_loop):
     """TwoHopEngine(relabel="degree") = the plain engine on (graph, table, seeds) renumbered by descending degree on the
