@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     static_assert(!MP || KP == 256, "multi-pass rows use 256-wide passes");
     constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1;    // K chunks staged per pass
     constexpr bool MULTI = MP || (CONCAT && KP == 256);  // more than one pass: group accumulators
-    static_assert(!PREP || !MULTI, "prepared planes exist for the one-pass shapes");
+    static_assert(!PREP || !MP, "prepared planes exist for rows of up to 256 floats");
     constexpr int KPASS = PCH * KP;                      // K columns per pass (<= 256)
     constexpr int KH = KPASS / 2, STEPS = KH / 16;
     constexpr int TG = MP ? SAGE_MP_TG : (MULTI ? 4 : 1);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         if (tid < 96) flags[tid] = 0;                         // ordered before the first staging by the barrier below
         lds_barrier();
         if constexpr (PREP)                                   // sage_prepare_weights left "W holds |w| >= 2^127 / Inf / NaN" behind the planes
-            if (tid == 0 && a.wsplit[(size_t)WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
+            if (tid == 0 && a.wsplit[(size_t)(CHUNKS / PCH) * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
         STAMP(0);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     // fully coalesced 1-KiB wave-instruction and nothing is split here (the strided fp32 loads + 16 split3
                     // per lane below took 8000 cycles per wave and ~15000 until the block's slowest wave had its slice:
                     // a third of the kernel, in-kernel s_memtime stamps)
-                    const uint4* wp = a.wsplit + ((size_t)wave * STEPS * 3) * 64 + lane;
+                    const uint4* wp = a.wsplit + ((size_t)(pass * WAVES + wave) * STEPS * 3) * 64 + lane;
 #pragma unroll
                     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 
 template <int KP, bool CONCAT, bool MP = false, bool PREP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
-    if constexpr (!CONCAT && !MP && !PREP)
+    if constexpr (!MP && !PREP)
         if (a.wsplit) return launch_bf16x3<KP, CONCAT, MP, true>(a, st);
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
@@ -584,24 +584,29 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     return SAGE_OK;
 }
 
-// W [out_dim, dim] fp32 -> three bf16 planes in the register order of dense_bf16x3_kernel<KP, false, false>:
-// prepared[((wave * STEPS + st) * 3 + plane) * 64 + lane] = 8 bf16 = plane(W[32 (wave & 3) + (lane & 31)][kk .. kk + 7]),
-// kk = (wave >> 2) * KP/2 + 16 st + 8 (lane >> 5); zeros outside [out_dim, dim].  One thread per (wave, st, lane).
-template <int KP>
+// W [out_dim, CHUNKS * dim] fp32 -> three bf16 planes in the register order of dense_bf16x3_kernel<KP, CONCAT, false, true>:
+// prepared[(((pass * 8 + wave) * STEPS + st) * 3 + plane) * 64 + lane] = 8 bf16 = plane(W[32 (wave & 3) + (lane & 31)][column(kk) .. + 7]),
+// kk = (wave >> 2) * KPASS/2 + 16 st + 8 (lane >> 5) inside the pass; column(kk) = chunk * dim + kk % KP in the [self | agg]
+// layout of encoders.py:54 (chunk = pass for the two-pass 512-deep layer, kk / KP when both chunks share one pass, 0 without
+// concat); zeros outside [out_dim, dim].  One thread per (pass, wave, st, lane); the trailer's .x = "W holds a huge value".
+template <int KP, bool CONCAT>
 __global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw, int dim, int out_dim, uint4* __restrict__ prepared) {
-    constexpr int KH = KP / 2, STEPS = KH / 16;
+    constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1, KPASS = PCH * KP, NPASS = (CONCAT ? 2 : 1) / PCH;
+    constexpr int KH = KPASS / 2, STEPS = KH / 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 8 * STEPS * 64) return;
-    uint4* trailer = prepared + (size_t)8 * STEPS * 3 * 64;   // .x != 0: W holds |w| >= 2^127 / Inf / NaN (zeroed by the launcher)
-    const int lane = idx & 63, st = (idx >> 6) % STEPS, wave = idx / (64 * STEPS);
+    if (idx >= NPASS * 8 * STEPS * 64) return;
+    uint4* trailer = prepared + (size_t)NPASS * 8 * STEPS * 3 * 64;   // zeroed by the launcher
+    const int lane = idx & 63, st = (idx >> 6) % STEPS, wave = (idx / (64 * STEPS)) % 8, pass = idx / (64 * STEPS * 8);
     const int row = 32 * (wave & 3) + (lane & 31);
     const int kk = (wave >> 2) * KH + 16 * st + 8 * (lane >> 5);
+    const int chunk = pass * PCH + kk / KP, kc = kk % KP;
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
     if (row < out_dim) {
+        const float* wr = W + (int64_t)row * ldw + (int64_t)chunk * dim;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (kk + e < dim) v0[e] = W[(int64_t)row * ldw + kk + e];
-            if (kk + 4 + e < dim) v1[e] = W[(int64_t)row * ldw + kk + 4 + e];
+            if (kc + e < dim) v0[e] = wr[kc + e];
+            if (kc + 4 + e < dim) v1[e] = wr[kc + 4 + e];
         }
     }
     if (huge4(v0) || huge4(v1)) atomicOr(&trailer->x, 1u);
@@ -611,11 +616,14 @@ __global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw,
     const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
     const bf16x8 pm = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
     const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-    uint4* dst = prepared + ((size_t)(wave * STEPS + st) * 3) * 64 + lane;
+    uint4* dst = prepared + ((size_t)((pass * 8 + wave) * STEPS + st) * 3) * 64 + lane;
     dst[0] = __builtin_bit_cast(uint4, ph);
     dst[64] = __builtin_bit_cast(uint4, pm);
     dst[128] = __builtin_bit_cast(uint4, pl);
 }
+
+// planes of the whole K range: 8 waves x (K / 32) steps x 3 planes x 64 lanes x 16 B, K = KP or (concat) 2 KP
+static size_t prepared_plane_bytes(int kp, bool concat) { return (size_t)8 * ((concat ? 2 : 1) * kp / 32) * 3 * 64 * 16; }
 
 int prepared_kp(int32_t dim, int32_t out_dim) {
     if (!sage_layer_dense_supported(dim, out_dim) || dim > 256) return 0;
@@ -624,10 +632,10 @@ int prepared_kp(int32_t dim, int32_t out_dim) {
 
 }  // namespace
 
-// Prepared weights exist for the non-concat contraction with dim <= 256 (the one-pass kernel); 0 = this layer shape takes W as it is.
+// Prepared weights exist for rows of up to 256 floats (the one- and two-pass kernels); 0 = this layer shape takes W as it is.
 extern "C" size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat) {
-    const int kp = concat ? 0 : prepared_kp(dim, out_dim);
-    return kp ? (size_t)8 * (kp / 32) * 3 * 64 * 16 + 16 : 0;      // the planes + a 16-byte trailer (huge-value mark)
+    const int kp = prepared_kp(dim, out_dim);
+    return kp ? prepared_plane_bytes(kp, concat != 0) + 16 : 0;      // the planes + a 16-byte trailer (huge-value mark)
 }
 
 extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t out_dim, int32_t concat, void* prepared,
@@ -639,14 +647,21 @@ extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t di
         return SAGE_EUNSUPPORTED;
     }
     SAGE_REQUIRE(prepared_bytes >= need, "prepare_weights: buffer %zu bytes < %zu", prepared_bytes, need);
-    SAGE_REQUIRE(ldw >= dim && sage_aligned(prepared, 16), "prepare_weights: ldw = %lld, buffer alignment", (long long)ldw);
+    SAGE_REQUIRE(ldw >= (concat ? 2 : 1) * (int64_t)dim && sage_aligned(prepared, 16), "prepare_weights: ldw = %lld, buffer alignment", (long long)ldw);
     const int kp = prepared_kp(dim, out_dim);
-    const int threads = 8 * (kp / 32) * 64, blocks = sage_cdiv(threads, 256);
+    const int threads = (int)((need - 16) / (3 * 16)), blocks = sage_cdiv(threads, 256);      // one thread per (pass, wave, step, lane)
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync((char*)prepared + need - 16, 0, 16, st) != hipSuccess) { sage_set_error("prepare_weights: hipMemsetAsync failed"); return SAGE_ELAUNCH; }
-    if (kp == 64) hipLaunchKernelGGL(prepare_weights_kernel<64>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
-    else if (kp == 128) hipLaunchKernelGGL(prepare_weights_kernel<128>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
-    else hipLaunchKernelGGL(prepare_weights_kernel<256>, dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, (uint4*)prepared);
+    uint4* out = (uint4*)prepared;
+    if (concat) {
+        if (kp == 64) hipLaunchKernelGGL((prepare_weights_kernel<64, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+        else if (kp == 128) hipLaunchKernelGGL((prepare_weights_kernel<128, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+        else hipLaunchKernelGGL((prepare_weights_kernel<256, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+    } else {
+        if (kp == 64) hipLaunchKernelGGL((prepare_weights_kernel<64, false>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+        else if (kp == 128) hipLaunchKernelGGL((prepare_weights_kernel<128, false>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+        else hipLaunchKernelGGL((prepare_weights_kernel<256, false>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+    }
     SAGE_CHECK_LAUNCH("prepare_weights_kernel");
     return SAGE_OK;
 }
@@ -668,7 +683,7 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     if (n == 0) return SAGE_OK;
     const DenseArgs a{x, ldx, dim, n, n_dev, n_off, concat ? self_tab : x, concat ? ld_self : ldx, concat ? (int)self_rows : n,
                       self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin,
-                      (!concat && dim <= 256) ? (const uint4*)weight_prepared : nullptr};
+                      dim <= 256 ? (const uint4*)weight_prepared : nullptr};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
     if (dim > 256) return concat ? launch_bf16x3<256, true, true>(a, st) : launch_bf16x3<256, false, true>(a, st);
 #ifndef SAGE_DENSE_FP32

@@ -303,8 +303,10 @@ int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t worksp
  * bf16 terms of x and of w (csrc/sage_dense.hip).  Splitting W [out_dim, dim] into its three bf16 planes,
  * laid out in the kernel's register order, depends only on W, so it can be done once per weight update instead
  * of by every block of every launch (a third of the contraction's time at BASELINE config 3).
- * sage_prepared_weight_bytes: size of the prepared form, 0 if this layer shape has none (concat encoder or
- * dim > 256: W is then used as it is).  Results are bit-identical with and without the prepared form.
+ * With concat != 0, W is [out_dim, 2 * dim] in the [self | agg] order of encoders.py:54.
+ * sage_prepared_weight_bytes: size of the prepared form (planes + a 16-byte trailer that marks a W holding
+ * |w| >= 2^127 / Inf / NaN), 0 if this layer shape has none (dim > 256: W is then used as it is).
+ * Results are bit-identical with and without the prepared form.
  * ------------------------------------------------------------------------- */
 size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat);
 int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t out_dim, int32_t concat,

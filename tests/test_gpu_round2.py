@@ -77,25 +77,27 @@ def test_role_pipeline_argument_checks():
         pipe.submit_many(torch.zeros(3, 64, dtype=torch.int32, device=DEV), [1, 2], torch.empty(4, 64, 16, device=DEV))
 
 
+@pytest.mark.parametrize("concat", [False, True])
 @pytest.mark.parametrize("d0,h1", [(256, 128), (128, 64), (64, 128), (100, 52)])
-def test_prepared_weight_planes_do_not_change_a_bit(d0, h1):
-    """sage_prepare_weights moves the bf16 split of W out of the contraction kernel; same planes, same MFMAs, same sums."""
-    graph, table, w1, w2 = _problem(d0=d0, h1=h1)
+def test_prepared_weight_planes_do_not_change_a_bit(d0, h1, concat):
+    """sage_prepare_weights moves the bf16 split of W out of the contraction kernel; same planes, same MFMAs, same sums -- for the
+    one-pass layer, for the concat encoder's [self | agg] weight staged as one pass (2 x dim <= 256) and as two (dim = 256)."""
+    graph, table, w1, w2 = _problem(d0=d0, h1=h1, concat=concat)
     rowptr, col = graph.to(DEV)
     seeds = torch.from_numpy(np.random.default_rng(3).choice(np.nonzero(graph.degrees() > 0)[0], 2048, replace=False).astype(np.int32)).to(DEV)
     outs = []
     for prep in (True, False):
-        eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), 15, 25, max_batch=2048, prepare_weights=prep)
+        eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), 15, 25, concat=concat, max_batch=2048, prepare_weights=prep)
         assert bool(eng.layout.layer1_split)
         assert (eng._model().w1_prepared is not None) == prep
         outs.append(eng.forward(seeds, seed=9).clone())
     assert _eq(outs[0], outs[1])
     # an in-place weight update is followed (version counter), as an optimizer step does it
-    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV).clone(), w2.to(DEV), 15, 25, max_batch=2048)
+    eng = TwoHopEngine(rowptr, col, table.to(DEV), w1.to(DEV).clone(), w2.to(DEV), 15, 25, concat=concat, max_batch=2048)
     a = eng.forward(seeds, seed=9).clone()
     eng.w1.mul_(-0.5)
     bb = eng.forward(seeds, seed=9).clone()
-    ref = TwoHopEngine(rowptr, col, table.to(DEV), eng.w1.clone(), w2.to(DEV), 15, 25, max_batch=2048, prepare_weights=False).forward(seeds, seed=9)
+    ref = TwoHopEngine(rowptr, col, table.to(DEV), eng.w1.clone(), w2.to(DEV), 15, 25, concat=concat, max_batch=2048, prepare_weights=False).forward(seeds, seed=9)
     assert not _eq(a, bb) and _eq(bb, ref)
 
 
@@ -348,6 +350,53 @@ def test_bf16x3_contraction_propagates_inf_and_nan_like_torch_mm(prepare):
         fin = torch.isfinite(ref)
         rows_fin = fin.all(1)
         assert_close_rowmax(got[rows_fin], (x.double() @ wt.double().t())[rows_fin], what="rows without a non-finite value")
+
+
+@pytest.mark.parametrize("d0", [256, 128])
+@pytest.mark.parametrize("prepare", [True, False])
+def test_bf16x3_concat_contraction_finite_and_non_finite(prepare, d0):
+    """The concat encoder's 2 x dim-deep contraction (two K passes at dim = 256, one at 128), W as prepared planes or as it is:
+    h1 = W_self . y + W_agg . x on a perfect-matching graph (frontier node b + j has the own row y_j and the neighbour mean x_j);
+    finite rows within 6 x 2^-23 sum|x||w| of fp64 (or twice torch's fp32 mm), Inf / NaN classes as torch.mm, huge weights through the exact path."""
+    gen = torch.Generator().manual_seed(21)
+    b, h1 = 4096, 128
+    n = 2 * b
+    x = torch.randn(b, d0, generator=gen)
+    y = torch.randn(b, d0, generator=gen) * torch.logspace(-3, 3, b)[:, None]
+    inf = float("inf")
+    x[9, 5], y[9, 6] = inf, 1.0
+    y[300, d0 - 1] = -inf
+    x[301, 0], y[301, 0] = inf, -inf
+    y[4000, 17] = float("nan")
+    rowptr = torch.arange(n + 1, dtype=torch.int64, device=DEV)
+    col = torch.cat([torch.arange(b, n), torch.arange(0, b)]).to(torch.int32).to(DEV)
+    table = torch.cat([x, y])                                  # node j < b: x_j; node b + j: y_j
+    w = torch.randn(h1, 2 * d0, generator=gen) / 20
+    w[w == 0] = 0.01
+    for huge_w in (False, True):
+        wt = w.clone()
+        if huge_w:
+            wt[7, 3], wt[90, d0 + 11] = 3e38, inf             # one in each half
+        eng = TwoHopEngine(rowptr, col, table.to(DEV), wt.to(DEV), torch.zeros(8, 2 * h1, device=DEV), 1, 1, concat=True, act1=ops.ACT_NONE,
+                           act2=ops.ACT_NONE, max_batch=b, nan_empty=False, prepare_weights=prepare)
+        assert bool(eng.layout.layer1_split) and (eng._model().w1_prepared is not None) == prepare
+        eng.forward(torch.arange(b, dtype=torch.int32, device=DEV), seed=1)
+        it = eng.intermediates()
+        first = it["first_frontier_row"]
+        s1 = it["s1_nodes"].cpu().numpy()[first:]
+        assert first == b and set(s1.tolist()) == set(range(b, n))
+        got = torch.empty(b, h1)
+        got[torch.from_numpy(s1 - b)] = it["h1"].cpu()[first:]
+        comb = torch.cat([y, x], 1)                            # encoders.py:54: [self | agg]
+        ref = comb @ wt.t()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        assert torch.equal(torch.isposinf(got), torch.isposinf(ref)) and torch.equal(torch.isneginf(got), torch.isneginf(ref))
+        cols_fin = torch.isfinite(wt).all(1) & (wt.abs().amax(1) < 1e30)      # outputs whose weights are ordinary numbers
+        rows_fin = torch.isfinite(ref[:, cols_fin]).all(1) & torch.isfinite(comb).all(1)
+        assert rows_fin.sum() > 4000 and cols_fin.sum() >= h1 - 2
+        err, _ = _norm_err(got[rows_fin][:, cols_fin], comb[rows_fin], wt[cols_fin])
+        e_torch, _ = _norm_err((comb[rows_fin] @ wt[cols_fin].t()), comb[rows_fin], wt[cols_fin])
+        assert err <= max(6.0, 2.0 * e_torch), f"concat contraction: {err:.2f} x 2^-23 sum|x||w| (torch fp32 mm: {e_torch:.2f})"
 
 
 def test_sigmoid_activation_matches_torch_over_the_fp32_range():
