@@ -274,7 +274,6 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     static_assert(!MP || KP == 256, "multi-pass rows use 256-wide passes");
     constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1;    // K chunks staged per pass
     constexpr bool MULTI = MP || (CONCAT && KP == 256);  // more than one pass: group accumulators
-    static_assert(!PREP || !MP, "prepared planes exist for rows of up to 256 floats");
     constexpr int KPASS = PCH * KP;                      // K columns per pass (<= 256)
     constexpr int KH = KPASS / 2, STEPS = KH / 16;
     constexpr int TG = MP ? SAGE_MP_TG : (MULTI ? 4 : 1);
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         if (tid < 96) flags[tid] = 0;                         // ordered before the first staging by the barrier below
         lds_barrier();
         if constexpr (PREP)                                   // sage_prepare_weights left "W holds |w| >= 2^127 / Inf / NaN" behind the planes
-            if (tid == 0 && a.wsplit[(size_t)(CHUNKS / PCH) * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
+            if (tid == 0 && a.wsplit[(size_t)npass * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
         STAMP(0);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
@@ -397,12 +396,14 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     // fully coalesced 1-KiB wave-instruction and nothing is split here (the strided fp32 loads + 16 split3
                     // per lane below took 8000 cycles per wave and ~15000 until the block's slowest wave had its slice:
                     // a third of the kernel, in-kernel s_memtime stamps)
-                    const uint4* wp = a.wsplit + ((size_t)(pass * WAVES + wave) * STEPS * 3) * 64 + lane;
+                    // wave-uniform base (SGPR pair) + one lane offset: 24 per-lane 64-bit addresses (the planes span 24 KiB, beyond a
+                    // load's immediate offset) cost 48 VGPRs and, in the 512-deep kernel, spills
+                    const uint4* wp = a.wsplit + (size_t)(pass * WAVES + __builtin_amdgcn_readfirstlane(wave)) * STEPS * 3 * 64;
 #pragma unroll
                     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
-                            const uint4 v = wp[(st * 3 + pl) * 64];
+                            const uint4 v = wp[(st * 3 + pl) * 64 + lane];
                             bw[st][pl] = __builtin_bit_cast(bf16x8, v);   // no use of v here: the loads stay in flight (the "W holds a
                         }                                                 // huge value" mark comes from the buffer's trailer, see below)
                     return;
@@ -536,8 +537,12 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 STAMP(stamp_i); ++stamp_i;
             }
         };
-        do_group((int)blockIdx.x);
-        for (int t0 = (int)blockIdx.x + TG * stride; t0 < ntiles; t0 += TG * stride) do_group(t0);
+        if constexpr (!MULTI) {
+            do_group((int)blockIdx.x);
+            for (int t0 = (int)blockIdx.x + TG * stride; t0 < ntiles; t0 += TG * stride) do_group(t0);
+        } else {                                              // W is (re)loaded inside every pass: nothing to keep in flight across the
+            for (int t0 = (int)blockIdx.x; t0 < ntiles; t0 += TG * stride) do_group(t0);   // loop header, and a second copy of the
+        }                                                     // body only adds register pressure (spills at 256 VGPRs)
         STAMP(39);
         // Tiles that held |x| >= 2^127 / Inf / NaN (or all tiles, when W does): the exact fp32 fma chain, outside the loop above
         // so that it costs the ordinary path no register.  Block-uniform; zero iterations on ordinary data.
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 
 template <int KP, bool CONCAT, bool MP = false, bool PREP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
-    if constexpr (!MP && !PREP)
+    if constexpr (!PREP)
         if (a.wsplit) return launch_bf16x3<KP, CONCAT, MP, true>(a, st);
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
@@ -589,17 +594,20 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
 // kk = (wave >> 2) * KPASS/2 + 16 st + 8 (lane >> 5) inside the pass; column(kk) = chunk * dim + kk % KP in the [self | agg]
 // layout of encoders.py:54 (chunk = pass for the two-pass 512-deep layer, kk / KP when both chunks share one pass, 0 without
 // concat); zeros outside [out_dim, dim].  One thread per (pass, wave, st, lane); the trailer's .x = "W holds a huge value".
-template <int KP, bool CONCAT>
+// MP (KP = 256): rows wider than 256 floats -- ceil(dim / 256) passes per chunk, column(kk) = chunk * dim + (pass % ppc) * 256 + kk.
+template <int KP, bool CONCAT, bool MP = false>
 __global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw, int dim, int out_dim, uint4* __restrict__ prepared) {
-    constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1, KPASS = PCH * KP, NPASS = (CONCAT ? 2 : 1) / PCH;
+    constexpr int PCH = (CONCAT && KP < 256) ? 2 : 1, KPASS = PCH * KP;
     constexpr int KH = KPASS / 2, STEPS = KH / 16;
+    const int ppc = MP ? (dim + KP - 1) / KP : 1;
+    const int npass = ((CONCAT ? 2 : 1) / PCH) * ppc;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NPASS * 8 * STEPS * 64) return;
-    uint4* trailer = prepared + (size_t)NPASS * 8 * STEPS * 3 * 64;   // zeroed by the launcher
+    if (idx >= npass * 8 * STEPS * 64) return;
+    uint4* trailer = prepared + (size_t)npass * 8 * STEPS * 3 * 64;   // zeroed by the launcher
     const int lane = idx & 63, st = (idx >> 6) % STEPS, wave = (idx / (64 * STEPS)) % 8, pass = idx / (64 * STEPS * 8);
     const int row = 32 * (wave & 3) + (lane & 31);
     const int kk = (wave >> 2) * KH + 16 * st + 8 * (lane >> 5);
-    const int chunk = pass * PCH + kk / KP, kc = kk % KP;
+    const int chunk = MP ? pass / ppc : pass * PCH + kk / KP, kc = MP ? (pass % ppc) * KP + kk : kk % KP;
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
     if (row < out_dim) {
         const float* wr = W + (int64_t)row * ldw + (int64_t)chunk * dim;
@@ -623,19 +631,22 @@ __global__ void prepare_weights_kernel(const float* __restrict__ W, int64_t ldw,
 }
 
 // planes of the whole K range: 8 waves x (K / 32) steps x 3 planes x 64 lanes x 16 B, K = KP or (concat) 2 KP
-static size_t prepared_plane_bytes(int kp, bool concat) { return (size_t)8 * ((concat ? 2 : 1) * kp / 32) * 3 * 64 * 16; }
+static size_t prepared_plane_bytes(int kp, bool concat, int dim) {
+    const int k_total = (concat ? 2 : 1) * (dim > 256 ? sage_cdiv(dim, 256) * 256 : kp);
+    return (size_t)8 * (k_total / 32) * 3 * 64 * 16;
+}
 
 int prepared_kp(int32_t dim, int32_t out_dim) {
-    if (!sage_layer_dense_supported(dim, out_dim) || dim > 256) return 0;
+    if (!sage_layer_dense_supported(dim, out_dim)) return 0;
     return dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
 }
 
 }  // namespace
 
-// Prepared weights exist for rows of up to 256 floats (the one- and two-pass kernels); 0 = this layer shape takes W as it is.
+// Prepared weights exist for every shape the contraction kernel takes; 0 = not a shape of that kernel.
 extern "C" size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat) {
     const int kp = prepared_kp(dim, out_dim);
-    return kp ? prepared_plane_bytes(kp, concat != 0) + 16 : 0;      // the planes + a 16-byte trailer (huge-value mark)
+    return kp ? prepared_plane_bytes(kp, concat != 0, dim) + 16 : 0;      // the planes + a 16-byte trailer (huge-value mark)
 }
 
 extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t out_dim, int32_t concat, void* prepared,
@@ -653,7 +664,10 @@ extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t di
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync((char*)prepared + need - 16, 0, 16, st) != hipSuccess) { sage_set_error("prepare_weights: hipMemsetAsync failed"); return SAGE_ELAUNCH; }
     uint4* out = (uint4*)prepared;
-    if (concat) {
+    if (dim > 256) {
+        if (concat) hipLaunchKernelGGL((prepare_weights_kernel<256, true, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+        else hipLaunchKernelGGL((prepare_weights_kernel<256, false, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
+    } else if (concat) {
         if (kp == 64) hipLaunchKernelGGL((prepare_weights_kernel<64, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
         else if (kp == 128) hipLaunchKernelGGL((prepare_weights_kernel<128, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
         else hipLaunchKernelGGL((prepare_weights_kernel<256, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);
@@ -683,7 +697,7 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
     if (n == 0) return SAGE_OK;
     const DenseArgs a{x, ldx, dim, n, n_dev, n_off, concat ? self_tab : x, concat ? ld_self : ldx, concat ? (int)self_rows : n,
                       self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin,
-                      dim <= 256 ? (const uint4*)weight_prepared : nullptr};
+                      (const uint4*)weight_prepared};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
     if (dim > 256) return concat ? launch_bf16x3<256, true, true>(a, st) : launch_bf16x3<256, false, true>(a, st);
 #ifndef SAGE_DENSE_FP32

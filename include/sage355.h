@@ -305,7 +305,7 @@ int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t worksp
  * of by every block of every launch (a third of the contraction's time at BASELINE config 3).
  * With concat != 0, W is [out_dim, 2 * dim] in the [self | agg] order of encoders.py:54.
  * sage_prepared_weight_bytes: size of the prepared form (planes + a 16-byte trailer that marks a W holding
- * |w| >= 2^127 / Inf / NaN), 0 if this layer shape has none (dim > 256: W is then used as it is).
+ * |w| >= 2^127 / Inf / NaN), 0 if the shape is not one of the contraction kernel's (out_dim > 128, dim % 4 != 0).
  * Results are bit-identical with and without the prepared form.
  * ------------------------------------------------------------------------- */
 size_t sage_prepared_weight_bytes(int32_t dim, int32_t out_dim, int32_t concat);

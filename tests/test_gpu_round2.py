@@ -78,10 +78,11 @@ def test_role_pipeline_argument_checks():
 
 
 @pytest.mark.parametrize("concat", [False, True])
-@pytest.mark.parametrize("d0,h1", [(256, 128), (128, 64), (64, 128), (100, 52)])
+@pytest.mark.parametrize("d0,h1", [(256, 128), (128, 64), (64, 128), (100, 52), (500, 50), (1433, 128)])
 def test_prepared_weight_planes_do_not_change_a_bit(d0, h1, concat):
     """sage_prepare_weights moves the bf16 split of W out of the contraction kernel; same planes, same MFMAs, same sums -- for the
-    one-pass layer, for the concat encoder's [self | agg] weight staged as one pass (2 x dim <= 256) and as two (dim = 256)."""
+    one-pass layer, for the concat encoder's [self | agg] weight staged as one pass (2 x dim <= 256) and as two (dim = 256), and for
+    rows wider than 256 floats (Pubmed 500, Cora 1433 padded to 1436: ceil(dim / 256) passes per chunk)."""
     graph, table, w1, w2 = _problem(d0=d0, h1=h1, concat=concat)
     rowptr, col = graph.to(DEV)
     seeds = torch.from_numpy(np.random.default_rng(3).choice(np.nonzero(graph.degrees() > 0)[0], 2048, replace=False).astype(np.int32)).to(DEV)
