@@ -200,6 +200,35 @@ def test_kernel_variants_behind_the_launch_tunables(env, tmp_path):
     assert res.returncode == 0 and "VARIANT_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
+# ------------------------------------------------------------------------------------------ size-independent properties at full size
+@pytest.mark.parametrize("relabel", [None, "degree"])
+def test_full_size_properties_homogeneity_permutation_sub_batch(relabel):
+    """BASELINE configs[2] at full size (2^20 nodes, 16 M edges, D0 = 256, 4096 seeds), properties that need no oracle and hold BIT
+    FOR BIT: (1) both layers are positively homogeneous, and a factor of two is exact in every step (the three-term bf16 split
+    included): out(2 X) = 2 out(X), out(4 W1, W2 / 2) = 2 out; (2) permuting the seeds permutes the rows (a node's draws are a
+    function of (key, node), and no sum depends on the frontier's order); (3) a sub-batch gives the same rows as the batch it
+    was cut from; (4) the same call twice gives the same bits."""
+    graph = rmat_graph(20, 16_000_000, seed=0, cache_dir=CACHE)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    table = torch.randn(graph.num_nodes, 256, generator=gen, device=DEV)
+    w1 = torch.randn(128, 256, generator=gen, device=DEV) / 16
+    w2 = torch.randn(128, 128, generator=gen, device=DEV) / 11
+    rowptr, col = graph.to(DEV)
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    seeds = torch.from_numpy(np.random.default_rng(1).choice(cand, 4096, replace=False).astype(np.int32)).to(DEV)
+    kw = dict(max_batch=4096, relabel=relabel)
+    eng = TwoHopEngine(rowptr, col, table, w1, w2, 15, 25, **kw)
+    a = eng.forward(seeds, seed=5).clone()
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    assert torch.equal(eng.forward(seeds, seed=5), a)
+    assert torch.equal(TwoHopEngine(rowptr, col, table * 2, w1, w2, 15, 25, **kw).forward(seeds, seed=5), a * 2)
+    assert torch.equal(TwoHopEngine(rowptr, col, table, w1 * 4, w2 * 0.5, 15, 25, **kw).forward(seeds, seed=5), a * 2)
+    perm = torch.randperm(4096, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    assert torch.equal(eng.forward(seeds[perm].contiguous(), seed=5), a[perm])
+    assert torch.equal(eng.forward(seeds[:1000].contiguous(), seed=5), a[:1000])
+    assert not torch.equal(eng.forward(seeds, seed=6), a)                # another key: other draws
+
+
 # ------------------------------------------------------------------------------------------ BASELINE configs at full size
 def _full_size_check(graph, d0, k1, k2, concat, self_loop, h1=128, h2=128, b=4096, relabel=None):
     gen = torch.Generator().manual_seed(0)
