@@ -19,22 +19,42 @@ RANK_SCRIPT = textwrap.dedent("""
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if "--fail" in sys.argv and dist.get_rank() == 1:
         sys.exit(3)
-    print("noise from rank", dist.get_rank(), flush=True)
+    if "--atomic-noise" in sys.argv:
+        sys.stdout.write("noise from rank %d\\n" % dist.get_rank()); sys.stdout.flush()      # one write(): cannot split another line
+    else:
+        print("noise", "from", "rank", dist.get_rank(), "x" * 200, flush=True)                 # several writes: may land INSIDE rank 0's line
     if dist.get_rank() == 0:
-        print(json.dumps({"metric": "m", "n_gpus": dist.get_world_size(), "max": t.item(), "argv": sys.argv[1:]}), flush=True)
+        line = json.dumps({"metric": "m", "n_gpus": dist.get_world_size(), "max": t.item(), "argv": sys.argv[1:]})
+        print(line, flush=True)
+        if "--no-file" not in sys.argv:
+            with open(os.environ["SAGE_BENCH_RESULT_FILE"], "w") as fh:
+                fh.write(line + "\\n")
     dist.barrier()
     dist.destroy_process_group()
 """)
 
 
 def test_self_launch_relays_rank0_line(tmp_path, capfd):
+    """Rank 0's line reaches the parent through the result file: the ranks share one stdout pipe, where another rank's output
+    can land in the middle of the line (seen here with a multi-write print, ~3 % of the runs)."""
     script = tmp_path / "rank.py"
     script.write_text(RANK_SCRIPT)
     rc = bench.self_launch(2, ["--gpus", "2", "--steps", "3"], script=str(script), timeout=300)
-    out = capfd.readouterr().out.strip().splitlines()
-    assert rc == 0 and len(out) == 1
+    cap = capfd.readouterr()
+    out = cap.out.strip().splitlines()
+    assert rc == 0 and len(out) == 1, cap.err[-2000:]
     line = json.loads(out[0])
     assert line["n_gpus"] == 2 and line["max"] == 2.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+
+
+def test_self_launch_falls_back_to_stdout_without_a_result_file(tmp_path, capfd):
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    rc = bench.self_launch(2, ["--no-file", "--atomic-noise"], script=str(script), timeout=300)
+    cap = capfd.readouterr()
+    out = cap.out.strip().splitlines()
+    assert rc == 0 and len(out) == 1, cap.err[-2000:]
+    assert json.loads(out[0])["argv"] == ["--no-file", "--atomic-noise"]
 
 
 def test_self_launch_fails_loudly_when_a_rank_dies(tmp_path, capfd):
