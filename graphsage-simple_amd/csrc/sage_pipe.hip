@@ -135,7 +135,9 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
     if (!fresh_slot)
         if (int rc = wait_on(p, RS, RL, slot)) return rc;
-#ifndef SAGE_PIPE_SKIP_S
+#ifndef SAGE_PIPE_SKIP_S   // diagnostic builds only (experiments/ab_build.sh).  _G and _D may be skipped alone (stale data downstream); _S and _L
+                           // only together with everything else ("events only"): the samplers fill and layer 2 wipes the frontier hash, and
+                           // one without the other leaves a full table behind (an outer sampler probing it took 67 ms per batch)
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0,
                                              SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
         return rc;
