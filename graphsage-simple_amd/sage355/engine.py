@@ -293,7 +293,12 @@ class TwoHopEngine:
                 int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream)
         rc = L.sage_forward2(*args) if stage_events is None else L.sage_forward2_profiled(*args, stage_events)
         if rc != 0:
-            native.check(rc, "forward2")
+            try:
+                native.check(rc, "forward2")
+            finally:
+                # a forward that stopped between two of its launches leaves sampled sets and frontier keys behind (layer 2's last
+                # block is what cleans up): give the next call a clean workspace rather than a full hash table
+                L.sage_forward2_init(args[0], self.workspace.data_ptr(), self.workspace.numel(), self.max_batch, args[-1])
         self._last_batch = b
         return out
 
@@ -364,6 +369,12 @@ class RolePipeline:
         self._wkey = self._weights_key()
         self._keep = []
 
+    def _check_usable(self):
+        # a submit that failed between two of its enqueues leaves a batch half-way through the role streams, its workspace dirty and
+        # its hand-off events unrecorded: later batches on that slot would wait for ever or sample into a full frontier table
+        if getattr(self, "_broken", False):
+            raise native.SageError("RolePipeline: an earlier submit failed half-way; synchronise, drop this pipe and create a new one")
+
     def _weights_key(self):
         w1, w2 = self.engines[0]._weights()
         return (w1.data_ptr(), w2.data_ptr(), w1._version, w2._version)
@@ -403,9 +414,11 @@ class RolePipeline:
     def submit_profiled(self, seeds, key, out, gather_events):
         """submit() with two hipEvent_t (a ctypes c_void_p * 2) recorded on stream G around the layer-1 gather."""
         self._sync_weights()
+        self._check_usable()
         rc = native.lib().sage_pipe_submit_profiled(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(),
                                                     out.stride(0), gather_events)
         if rc != 0:
+            self._broken = True
             native.check(rc, "pipe_submit_profiled")
 
     def submit(self, seeds, key, out):
@@ -416,9 +429,11 @@ class RolePipeline:
             raise native.SageError("RolePipeline.submit: seeds must be a contiguous int32 device tensor of `batch` ids")
         if out.shape != (self.batch, self.h2) or out.dtype != torch.float32 or not out.is_cuda or out.stride(1) != 1:
             raise native.SageError("RolePipeline.submit: `out` must be a [batch, h2] fp32 device tensor with unit inner stride")
+        self._check_usable()
         self._sync_weights()
         rc = native.lib().sage_pipe_submit(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), out.stride(0))
         if rc != 0:
+            self._broken = True
             native.check(rc, "pipe_submit")
 
     def submit_many(self, seeds, keys, out, segment_start=False):
@@ -436,9 +451,11 @@ class RolePipeline:
             raise native.SageError("RolePipeline.submit_many: `out` must be a contiguous [slots >= depth, batch, h2] fp32 device tensor")
         self._sync_weights()
         karr = (ctypes.c_uint64 * n)(*[int(k) & 0xFFFFFFFFFFFFFFFF for k in keys])
+        self._check_usable()
         rc = native.lib().sage_pipe_submit_many(self._h, seeds.data_ptr(), self.batch, karr, n, out.data_ptr(), out.stride(1),
                                                 out.stride(0), out.shape[0], 1 if segment_start else 0)
         if rc != 0:
+            self._broken = True
             native.check(rc, "pipe_submit_many")
 
     def synchronize(self):
