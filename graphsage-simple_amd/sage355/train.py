@@ -220,12 +220,17 @@ class EngineTrainer:
                                                    P(self._grad_h1), L.max_s1, h1p, st), "gather_mean_backward (layer 2)")
         if self.concat:
             self._grad_h1[:b] += g_x2[:, :h1p]
-        # ---- layer 1 backward: only dW1 (the table is frozen); agg1 recomputed on the live rows
+        # ---- layer 1 backward: only dW1 (the table is frozen); agg1 from the workspace (split layer) or recomputed on the live rows
         self_row1 = s1_nodes if e.agg_self_loop else None
-        ops.gather_mean(e.table, nbr1, cnt1, self_row=self_row1, any_nonempty=self._any, n_dev=self._nlive, out=self._agg1)
+        if L.layer1_split:
+            # the split layer (sliced gather + contraction) left the means of this very forward in the workspace: no second gather
+            agg1 = e._view(L.agg1, L.max_s1 * d0p, torch.float32).view(L.max_s1, d0p)
+        else:
+            ops.gather_mean(e.table, nbr1, cnt1, self_row=self_row1, any_nonempty=self._any, n_dev=self._nlive, out=self._agg1)
+            agg1 = self._agg1
         g_w1p = torch.zeros_like(w1p)
         native.check(lib.sage_linear_act_backward(P(e.table) if self.concat else None, e.table_ld, P(s1_nodes) if self.concat else None,
-                                                  P(self._agg1), self._agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, e.act1, P(h1), h1p,
+                                                  P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, e.act1, P(h1), h1p,
                                                   P(self._grad_h1), h1p, L.max_s1, P(self._nlive), P(g_w1p), g_w1p.stride(0), None, 0, st),
                      "linear_act_backward (layer 1)")
         # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
