@@ -8,7 +8,7 @@
 //                                                          split across blockIdx.z, fp32 atomics
 //   grad_table[row(nbr[r,j])] += grad_agg[r] / c           fp32 atomics (mean backward = scatter)
 // One generic 64x128x32 MFMA tile kernel with functor operands serves both GEMMs; the training
-// layers are small (Cora / Pubmed scale), so operand loads are simple guarded scalar loads.
+// operand loads are guarded scalar loads along the index that is contiguous in memory, transposed into LDS.
 #include "sage_internal.h"
 
 namespace {
@@ -64,20 +64,41 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const floa
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     const int kk = tid & 31, rr = tid >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const int gk = k0 + kk;
+        // Operand tiles go to LDS as [row][k]; the LOADS run along whichever index is contiguous in memory (LDP = 33: the
+        // transposing stores are conflict-free).  With k across the lanes for every operand (the first version: "layers are
+        // small") the grad_W operands -- dZ(k, m) and X(k, n), both row-major in k -- were 4-byte loads one row apart:
+        // 90 us for the 23.6 k x 256 x 128 weight gradient of config 3.
+        if constexpr (MODE == 0) {
+            const int gk = k0 + kk;
 #pragma unroll
-        for (int i = 0; i < BM / 8; ++i) {
-            const int row = rr + 8 * i, gm = m0 + row;
-            float v = 0.f;
-            if (gm < M && gk < kend) v = (MODE == 0) ? dz(gm, gk) : dz(gk, gm);
-            As[row * LDP + kk] = v;
-        }
+            for (int i = 0; i < BM / 8; ++i) {                       // dZ(m, k): k contiguous
+                const int row = rr + 8 * i, gm = m0 + row;
+                float v = 0.f;
+                if (gm < M && gk < kend) v = dz(gm, gk);
+                As[row * LDP + kk] = v;
+            }
 #pragma unroll
-        for (int i = 0; i < BN / 8; ++i) {
-            const int row = rr + 8 * i, gn = nb0 + row;
-            float v = 0.f;
-            if (gn < N && gk < kend) v = (MODE == 0) ? W[(int64_t)gk * ldw + gn] : x(gk, gn);
-            Bs[row * LDP + kk] = v;
+            for (int i = 0; i < BN * BK / 256; ++i) {                // W[k][n]: n contiguous
+                const int idx = tid + 256 * i, nl = idx % BN, kl = idx / BN, gn = nb0 + nl, gk2 = k0 + kl;
+                float v = 0.f;
+                if (gn < N && gk2 < kend) v = W[(int64_t)gk2 * ldw + gn];
+                Bs[nl * LDP + kl] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BM * BK / 256; ++i) {                // dZ(k, m): m contiguous
+                const int idx = tid + 256 * i, ml = idx % BM, kl = idx / BM, gm = m0 + ml, gk2 = k0 + kl;
+                float v = 0.f;
+                if (gm < M && gk2 < kend) v = dz(gk2, gm);
+                As[ml * LDP + kl] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BN * BK / 256; ++i) {                // X(k, n): n contiguous
+                const int idx = tid + 256 * i, nl = idx % BN, kl = idx / BN, gn = nb0 + nl, gk2 = k0 + kl;
+                float v = 0.f;
+                if (gn < N && gk2 < kend) v = x(gk2, gn);
+                Bs[nl * LDP + kl] = v;
+            }
         }
         __syncthreads();
         if (wave_active) {
