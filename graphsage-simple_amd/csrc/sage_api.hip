@@ -35,6 +35,7 @@ const sage_tunables_t& sage_tunables() {
         x.gather_trip = env_int("SAGE_G_TRIP", 16, 8, 16) >= 16 ? 16 : 8;
         x.gather_variant = env_int("SAGE_G_VARIANT", 1, 0, 2);
         x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU, 32, 512);
+        x.bwd_blocks = env_int("SAGE_BWD_BLOCKS", 512, 16, 4096);
         const int so = env_int("SAGE_SO_THREADS", 1024, 256, 1024);
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);

@@ -204,7 +204,7 @@ extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, 
     }
     if (grad_weight) {
         const int tiles = sage_cdiv(out_dim, BM) * sage_cdiv(K, BN);
-        const int ksplit = max(1, min(sage_cdiv(n, 4 * BK), (2 * kNumCU) / tiles));
+        const int ksplit = max(1, min(sage_cdiv(n, 4 * BK), sage_tunables().bwd_blocks / tiles));
         dim3 grid(sage_cdiv(out_dim, BM), sage_cdiv(K, BN), ksplit);
         hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, grad_weight, ldgw, ksplit, n_dev);
         SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_w>");

@@ -75,7 +75,7 @@ def test_engine_gradients_match_fp64_autograd_on_the_same_sets(gcn, d0, h1, rela
 def test_engine_step_at_config3_size_gradients_and_step_time():
     """BASELINE configs[2] dimensions (R-MAT 2^20 / 16 M edges, D0 = 256, H = 128/128, fanout 15/25, 4096 seeds, degree layout):
     the step's gradients against fp64 autograd on the ~23.5 k-row layer the engine sampled, and a step in under 1.5 ms
-    (measured 0.42 ms = 1e7 seeds/s, experiments/train_big.py)."""
+    (measured 0.39 ms = 1e7 seeds/s, experiments/train_big.py)."""
     import time
     graph = rmat_graph(20, 16_000_000, seed=0, cache_dir=os.environ.get("SAGE_CACHE", "/tmp/sage_cache"))
     gen = torch.Generator(device=DEV).manual_seed(0)
