@@ -489,6 +489,11 @@ def main():
                              "(overlap with the other stages' kernels included)" if insitu_ms is not None else
                              "raw HIP-event interval around the launch on its own stream, one batch in flight"),
             "kernel_ms_alone": round(alone_ms, 5), "frac_alone": round(l1 / (alone_ms * 1e-3) / HBM_PEAK, 4),
+            # the basis of round 1's figure (kernel alone, its own bytes incl. the write of the means): 0.388 there
+            "frac_alone_own_bytes": round(own / (alone_ms * 1e-3) / HBM_PEAK, 4),
+            "frac_note": ("`frac` / `kernel_ms` are measured with the other stages' kernels of three more batches co-resident (role "
+                          "pipeline): they say what share of the chip the kernel gets there, not how good it is; the kernel alone: "
+                          "`frac_alone` (SURVEY-8(d) bytes) and `frac_alone_own_bytes`" if insitu_ms is not None else ""),
             "empty_event_pair_ms": round(gap, 5),
             "stage_ms_alone": {"sample_outer": round(float(stage[0]), 5), "sample_inner": round(float(stage[1]), 5),
                                "layer1_gather": round(float(stage[2]), 5), "layer1_contract": round(float(stage[3]), 5),

@@ -16,6 +16,9 @@ timeout -k 10 300 python bench.py --cpu-seconds 0 --exec replay --streams 2 > "$
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --cpu-seconds 0 \
     > "$O/bench_under_rocprof.json" 2> "$O/stats.log"; echo "stats rc=$?"
+# the same kernels with ONE batch in flight (host-enqueued on one stream): what each costs alone
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_alone" -- python3 "$R/bench.py" --exec direct --streams 1 \
+    --steps 100 --warmup 10 --no-parity --cpu-seconds 0 --no-variant > "$O/bench_alone_under_rocprof.json" 2> "$O/stats_alone.log"; echo "stats_alone rc=$?"
 PMC_CMD="python3 $R/bench.py --steps 12 --warmup 3 --exec direct --streams 1 --no-parity --cpu-seconds 0 --preheat-seconds 0"
 for group in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_REQ_sum" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \

@@ -54,6 +54,19 @@ if stats:
         w.writerows(rows[:40])
 
 
+stats1 = sorted(glob.glob(os.path.join(src, "stats_alone", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+if stats1:
+    rows = list(csv.DictReader(open(stats1[-1])))
+    rows.sort(key=lambda r: (short(r["Name"]) is None, -float(r["TotalDurationNs"])))
+    for r in rows:
+        if len(r["Name"]) > 160:
+            r["Name"] = r["Name"][:157] + "..."
+    with open(os.path.join(here, f"{tag}_kernel_stats_one_batch_in_flight.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows[:40])
+
+
 def per_kernel(pattern):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
