@@ -50,4 +50,15 @@ for relabel in (None, "degree"):
     dt = (time.perf_counter() - t0) / (steps - 10)
     ls = [float(x) for x in losses]
     print(f"   {dt * 1e3:.3f} ms per SGD step of {b} seeds = {b / dt:.3g} seeds/s; loss {ls[0]:.4f} -> {ls[-1]:.4f}", flush=True)
+    ring = torch.stack(seeds[:32])
+    loss_t = tr.capture_step(ring, [500 + i for i in range(32)], labels)
+    for _ in range(8):
+        tr.replay_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(64):
+        tr.replay_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 64
+    print(f"   captured step (one hipGraph per step): {dt * 1e3:.3f} ms = {b / dt:.3g} seeds/s; loss {float(loss_t):.4f}", flush=True)
     del tr

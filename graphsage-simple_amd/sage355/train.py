@@ -159,6 +159,8 @@ class EngineTrainer:
         self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=dev)
         self._agg1 = torch.zeros(L.max_s1, e.d0p, device=dev)
         self._any = torch.ones(1, dtype=torch.int32, device=dev)
+        self._out_q = None
+        self._step_graph = None
 
     def parameters(self):
         return [self.w1, self.w2, self.w_cls]
@@ -177,8 +179,14 @@ class EngineTrainer:
         native, ops, e = self._native, self._ops, self.engine
         lib = native.lib()
         st = native.stream_handle()
-        b = seeds.shape[0]
-        out = e.forward(seeds, seed=key)                                   # sample, frontier, sample, layer 1, layer 2
+        if seeds is None:                                                  # the batch at the engine's queue cursor (capturable step)
+            b = e._queue_batch
+            if self._out_q is None or self._out_q.shape[0] != b:
+                self._out_q = torch.empty(b, e.h2, device=e.device)
+            out = e.forward_queued(self._out_q)
+        else:
+            b = seeds.shape[0]
+            out = e.forward(seeds, seed=key)                               # sample, frontier, sample, layer 1, layer 2
         L = e.layout
         if L.max_s1 != self._grad_h1.shape[0]:                             # the engine re-reserved for a bigger batch
             self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=out.device)
@@ -255,6 +263,52 @@ class EngineTrainer:
         self.w2.add_(g2, alpha=-self.lr)
         self.w_cls.add_(gc, alpha=-self.lr)
         return loss
+
+
+    # ---- the whole step as ONE hipGraph ("graph-capturable fwd+bwd") ------------------------------------------------
+    def capture_step(self, seeds_ring, keys, labels_by_node):
+        """seeds_ring: int32 device tensor [S, B] of mini-batches, keys: S sampler keys, labels_by_node: int64 device tensor [N].
+        Captures forward + loss + backward + SGD of the batch at the engine's queue cursor into one torch.cuda.CUDAGraph:
+        replay_step() then trains on batch after batch of the ring (wrapping around) with a single graph launch each, nothing
+        read from the host: the seeds and the sampler key come from the device-side ring (sage_batch_t), the labels are
+        gathered by the ids at the cursor, the weight planes are re-prepared inside the graph after every update.
+        -> the static device scalar that holds the last replayed step's loss."""
+        e = self.engine
+        if dist.world_size() > 1:
+            raise self._native.SageError("capture_step: single-process only (the data-parallel step has a collective per step)")
+        e.set_queue(seeds_ring, keys)
+        ring, nring = e._queue_seeds, seeds_ring.shape[0]
+        labels_by_node = labels_by_node.to(e.device)
+        self._loss_static = torch.zeros((), device=e.device)
+
+        def one():
+            cur = torch.remainder(e._cursor.to(torch.int64), nring)       # read BEFORE the forward's last kernel advances the cursor
+            ids = ring.index_select(0, cur)[0]
+            labels = labels_by_node.index_select(0, ids.to(torch.int64))
+            self._loss_static.copy_(self.step(None, labels, None))
+
+        saved = [w.clone() for w in self.parameters()]
+        side = torch.cuda.Stream(device=e.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                     # warm-up outside capture: a real step, undone below
+            one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one()
+        with torch.no_grad():
+            for w, w0 in zip(self.parameters(), saved):
+                w.copy_(w0)
+        e._model()                                                        # planes of the restored W1
+        e.rewind(0)
+        torch.cuda.synchronize()
+        self._step_graph = g
+        return self._loss_static
+
+    def replay_step(self):
+        self._step_graph.replay()
+        return self._loss_static
 
 
 def run_engine_training(graph, feat_data, labels, num_classes, seed=1, epochs=1, batch_size=128, ref_batching=False, lr=0.7,
