@@ -278,8 +278,14 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 || !WREG) ? 4 : 2) void la
 // groups fetch different neighbours (the sliced gather's trick) with the whole neighbour list in flight, and the
 // groups meet in xor-shuffles: counts+ids -> rows -> LDS -> MFMA is two dependent trips instead of seven.
 // Waves 0..7 own the 16-column output tiles; their W slices are requested before the gather and stay in VGPRs.
+// The concat layer holds a 2 x KP-deep W slice (64 VGPRs at KP = 128) next to the gather's rows in flight: under the 128-VGPR cap of
+// "4 waves per SIMD" it spilled (64 bytes of scratch per lane); with room for 172 it does not, and nothing shares a CU with the
+// concat layers' kernels anyway -- concat forward at config 3 101.5 -> 89 us, config 5 90 -> 83 us (same-box A/B).
+#ifndef SAGE_T16_CONCAT_MIN_WAVES
+#define SAGE_T16_CONCAT_MIN_WAVES 2
+#endif
 template <int KP, bool CONCAT, int INFLIGHT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 4) void layer_tile16_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(WAVES * 64, CONCAT ? SAGE_T16_CONCAT_MIN_WAVES : 4) void layer_tile16_kernel(const FusedArgs a) {
     // WAVES = 16: one row per wave (fastest alone).  WAVES = 8: two rows per wave, 512-thread blocks -- half the wave
     // slots and VGPRs per block, so the block finds room on a CU that other batches' kernels already share (sage_pipe.hip:
     // a 1024-thread block needs 16 free wave slots and 384 VGPRs per SIMD on ONE CU and waited for whole gathers to drain).
@@ -439,7 +445,10 @@ int launch_tile16(const FusedArgs& a, hipStream_t st) {
 #ifndef SAGE_T16_INFLIGHT
 #define SAGE_T16_INFLIGHT 7
 #endif
-    constexpr int INFLIGHT = CONCAT ? 7 : SAGE_T16_INFLIGHT;
+#ifndef SAGE_T16_INFLIGHT_CONCAT
+#define SAGE_T16_INFLIGHT_CONCAT 7
+#endif
+    constexpr int INFLIGHT = CONCAT ? SAGE_T16_INFLIGHT_CONCAT : SAGE_T16_INFLIGHT;
     const int tiles = sage_cdiv(a.n, 16);
     const int grid = min(tiles, sage_tunables().tile16_grid);
     if (sage_tunables().tile16_waves == 8)
