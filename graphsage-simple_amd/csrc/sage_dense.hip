@@ -309,6 +309,23 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
 
         f32x4 xr[PCH][PASSES];
         int xc[PASSES];                                       // neighbour counts of the requested rows (0/0 rule only)
+        // concat encoder: rows of the nodes' own features are fetched through an index (s1_nodes).  Index and row in one request
+        // are two DEPENDENT round trips in front of every tile's MFMA loop; the indices of a block's next tile are requested
+        // with the current tile's rows instead and are there when that tile's rows are asked for.
+        // (Two-pass 512-deep layer only: same-box A/B, concat forward at config 3 86.6 -> 83.7 us.  In the one-pass concat kernel
+        // (KP <= 128) the four index registers cross an occupancy step, 167 -> 172 VGPRs, and although the kernel alone gains --
+        // 28.8 -> 26.3 us at config 5 -- the pipeline loses: 82.5 -> 86.0 us, three runs each.)
+        constexpr bool SELF_AHEAD = CONCAT && !MP && KP == 256;
+        int sidx[SELF_AHEAD ? PASSES : 1];
+        auto request_self_index = [&](int tile) {
+            if constexpr (SELF_AHEAD) {
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    const int g = min(tile * M + wave * RPW + p * RPP + sg, nn - 1);
+                    sidx[p] = a.self_index ? a.self_index[g] : g;
+                }
+            }
+        };
         // global -> VGPRs, no wait.  No lane-dependent branch anywhere near these loads: rows past the end and columns past
         // the row width are requested from clamped addresses and masked when the tile is staged.  (`x = 0; if (valid) x = load`
         // compiles to a divergent branch whose join COPIES the loaded registers -- a use, so the compiler waited for the loads
@@ -326,12 +343,17 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                         // of the NEXT batch, which runs beside this kernel (same-box A/B with the sampler's nt loads: -0.8 us per forward)
                         xr[pc][p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff));
                         if (nan_rule) xc[p] = a.cnt[g];
+                    } else if constexpr (SELF_AHEAD) {
+                        // the node's own row: its index was requested one tile ago (sidx), so this load does not wait for it
+                        xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + (int64_t)min(max(sidx[p], 0), a.self_rows - 1) * a.ld_self + coff);
                     } else {
                         const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1)
                                                        : (int64_t)min(g, a.self_rows - 1);
                         xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + s * a.ld_self + coff);
                     }
                 }
+                if constexpr (SELF_AHEAD)
+                    if (!is_agg) request_self_index(tile + stride);       // a block's tiles come in this order in every pass structure but MP
             }
         };
         int stage_seq = 0;                                    // stagings so far (block-uniform): the tag a "huge value" mark carries,
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         if constexpr (PREP)                                   // sage_prepare_weights left "W holds |w| >= 2^127 / Inf / NaN" behind the planes
             if (tid == 0 && a.wsplit[(size_t)npass * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
         STAMP(0);
+        request_self_index((int)blockIdx.x);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
 
         // W slice -> three bf16 planes in VGPRs: bw[st][plane] = W[n0+i][kk .. kk+7], kk = pass*KPASS + kgroup*KH + 16 st + 8 h
