@@ -92,6 +92,31 @@ __device__ inline int sage_hash_insert(int32_t* __restrict__ keys, uint32_t mask
 
 __device__ inline int sage_lane() { return (int)(threadIdx.x & (kWave - 1)); }
 
+// ---- cache policy of the intermediates that cross a kernel boundary (the layer-1 means, h1) -------------------------
+// 16-byte store / load of a row piece another KERNEL consumes (never another workgroup of the same launch).
+// Policy (MI355X_MICROARCH.md, "stores of each flavour"): plain and nt stores KEEP the written line in the XCD's L2 --
+// 3 MB of means per XCD and launch that evict the gather's hub slices -- while sc1 stores write through and DROP it.
+//   0 plain   1 nt (round 1-2 default)   2 sc1   3 sc0 sc1   4 nt sc1
+// A/B knobs of experiments/r03 (-DSAGE_AGG_STORE=..., -DSAGE_H1_STORE=..., -DSAGE_AGG_LOAD=...); the defaults are what measured best.
+using sage_f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int POLICY>
+__device__ __forceinline__ void sage_store_stream(sage_f32x4* p, const sage_f32x4 v) {
+    if constexpr (POLICY == 0) *p = v;
+    else if constexpr (POLICY == 1) __builtin_nontemporal_store(v, p);
+    else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+#ifndef SAGE_AGG_STORE
+#define SAGE_AGG_STORE 1
+#endif
+#ifndef SAGE_H1_STORE
+#define SAGE_H1_STORE 1
+#endif
+#ifndef SAGE_AGG_LOAD          // 0 plain, 1 nt
+#define SAGE_AGG_LOAD 1
+#endif
+
 __device__ inline uint32_t sage_philox_word(const Philox4& p, int w) {
     return w == 0 ? p.v[0] : w == 1 ? p.v[1] : w == 2 ? p.v[2] : p.v[3];
 }

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     if (is_agg) {
                         // streaming load: every row of the means is read once, and left in L2 it would evict the gather's hub rows
                         // of the NEXT batch, which runs beside this kernel (same-box A/B with the sampler's nt loads: -0.8 us per forward)
-                        xr[pc][p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff));
+                        if constexpr (SAGE_AGG_LOAD == 1) xr[pc][p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff));
+                        else xr[pc][p] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff);
                         if (nan_rule) xc[p] = a.cnt[g];
                     } else if constexpr (SELF_AHEAD) {
                         // the node's own row: its index was requested one tile ago (sidx), so this load does not wait for it
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                                                                    // the tile keep the MFMA result, so a row never depends on its tile mates
                         float* dst = a.out + (int64_t)g * a.ldo + col;
                         if (col + 3 < a.out_dim && vec_store) {
-                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                            sage_store_stream<SAGE_H1_STORE>(reinterpret_cast<f32x4*>(dst), v);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)

@@ -80,12 +80,9 @@ __device__ __forceinline__ void gather_sliced_block(
             V res;
             if (ceff > 0) res = acc * (1.0f / (float)ceff);
             else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
-#ifndef SAGE_NO_NT_STORES   // streaming stores: the next kernel reads these rows from other XCDs anyway, and dirty lines left in L2 are
-                            // written back at the kernel boundary, on the critical path (gather 49.4 -> 48.3 us, contraction 22.2 -> 21.3)
-            __builtin_nontemporal_store(res, reinterpret_cast<V*>(out + (int64_t)r * ldo + c0));
-#else
-            *reinterpret_cast<V*>(out + (int64_t)r * ldo + c0) = res;
-#endif
+            // streaming stores: the next kernel reads these rows from other XCDs anyway, and dirty lines left in L2 are
+            // written back at the kernel boundary, on the critical path (gather 49.4 -> 48.3 us, contraction 22.2 -> 21.3)
+            sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
         }
     }
 }
@@ -206,7 +203,7 @@ __device__ __forceinline__ void gather_sliced_block_pipelined(
                 V res;
                 if (ceff > 0) res = acc * (1.0f / (float)ceff);
                 else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
-                __builtin_nontemporal_store(res, reinterpret_cast<V*>(out + (int64_t)r * ldo + c0));
+                sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
             }
         }
         r0 = rn0;
@@ -295,7 +292,7 @@ __device__ __forceinline__ void gather_sliced_block_rows(
             V res;
             if (ceff > 0) res = acc * (1.0f / (float)ceff);
             else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
-            __builtin_nontemporal_store(res, reinterpret_cast<V*>(out + (int64_t)r * ldo + c0));
+            sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
         }
     }
 }
