@@ -90,6 +90,10 @@ def parse():
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[] preset: 3 = the bench line (default); 2 = Pubmed topology D0=500 H=50/128 fanout 10/25 "
                          "B=256; 4 = R-MAT 2^23 / 128 M edges; 5 = ogbn-products-shaped 2.4 M nodes / 62 M edges D0=100 fanout 20/25")
+    ap.add_argument("--scale-variant", choices=["auto", "on", "off"], default=os.environ.get("SAGE_SCALE_VARIANT", "auto"),
+                    help="N > 1 (auto) or always (on): after the headline run, time the same K steps on BASELINE configs[3] (R-MAT 2^23 / "
+                         "128 M edges, the workload BASELINE names for the 1/2/4/8 scaling curve) and report it as "
+                         "config.variants.configs3_rmat23; `value` stays on configs[2]")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsing N > 1 on a 1-GPU box)")
@@ -259,15 +263,20 @@ def main():
     base = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, **ekw)
     nstreams = max(1, args.streams)
 
-    # ---- parity gate: one batch against the fp64 oracle on the GPU's own sampled sets ----
+    # ---- parity gate: one batch against the fp64 oracle on the GPU's own sampled sets.  The batch is the LAST one of the timed
+    #      region: after the timed region the output the role pipeline left for that very batch is compared with this one bit
+    #      for bit (gate the path that is timed, at the size it is timed) ----
     parity_err = None
+    gate_i = total_steps - 1
+    gate_out = None
     if not args.no_parity and rank == 0:
         from oracle import ref_sparse
-        o = base.forward(seeds_dev[0], seed=sampler_seed[0]).cpu()
+        gate_out = base.forward(seeds_dev[gate_i], seed=sampler_seed[gate_i]).clone()
+        o = gate_out.cpu()
         it = base.intermediates()            # ids below are the engine's INTERNAL ones: index its own table copy with them
         first = it["first_frontier_row"]
         s1, nbr1, cnt1 = it["s1_nodes"].cpu().numpy(), it["nbr1"].cpu().numpy(), it["cnt1"].cpu().numpy()
-        seeds_int = seeds_host[0] if base._new_of_old is None else base._new_of_old[torch.from_numpy(seeds_host[0]).long().to(dev)].cpu().numpy()
+        seeds_int = seeds_host[gate_i] if base._new_of_old is None else base._new_of_old[torch.from_numpy(seeds_host[gate_i]).long().to(dev)].cpu().numpy()
         ref = ref_sparse.two_hop_forward(base.table.cpu(), w1.cpu(), w2.cpu(), seeds_int, it["nbr2"].cpu().numpy(),
                                          it["cnt2"].cpu().numpy(), s1[first:], nbr1[first:], cnt1[first:], gcn=not concat,
                                          agg_gcn=args.self_loop,
@@ -372,6 +381,24 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * b * args.steps / elapsed
 
+    # ---- the timed path's own output, checked AFTER the clock stopped: what the timed execution mode left for the gate batch
+    #      (the last timed step) against the oracle-gated single forward of the same (seeds, key), bit for bit ----
+    timed_check = None
+    if gate_out is not None:
+        if pipe is not None:
+            got = pipe_out[gate_i % pipe_out.shape[0]]
+        elif exec_mode == "replay" and bpr > 1:
+            got = engines[(gate_i // bpr) % nstreams]._graph_out[gate_i % bpr]
+        else:
+            got = outs[gate_i % nstreams]
+        same = bool(torch.equal(got, gate_out))
+        timed_check = {"batch": gate_i, "bit_identical_to_oracle_gated_forward": same,
+                       "what": "output slot the timed region wrote for its last step vs TwoHopEngine.forward(same seeds, same key), "
+                               "which passed the fp64-oracle gate above"}
+        if not same:
+            raise SystemExit(f"timed-path check failed: the {exec_mode} execution's output for step {gate_i} differs from the single forward "
+                             f"(max abs diff {(got - gate_out).abs().max().item():.3e})")
+
     workload = (f"BASELINE configs[{args.config - 1}]: "
                 + ("Pubmed topology (19717 nodes)" if args.config == 2 else
                    f"R-MAT 2^{args.scale} / {args.edges} edges" + (f" truncated to {n} nodes" if args.truncate else f" ({n} nodes)"))
@@ -467,12 +494,15 @@ def main():
         sizes = st.mean(0)
         per_edge = 4 * d0 * sizes[2] + 4 * h1 * sizes[0]
         traffic = None
+        traffic_source = None
         tfile = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))          # PMC passes are separate runs (profiles/collect.sh): only valid
                 if tj.get("workload", workload) == workload and tj.get("engine_layout") == (relabel or "input") and split:
                     traffic = tj.get("layer1_hbm_bytes_per_launch")
+                    traffic_source = ("profiles/traffic.json <- " + str(tj.get("source")) + " (builder's rocprofv3 --pmc pass of this "
+                                      "command on an MI355X, committed; NOT collected by this run: PMC needs the profiler)")
             except Exception:
                 traffic = None
         achieved = l1 / (kernel_ms * 1e-3) / 1e9
@@ -480,7 +510,7 @@ def main():
             "bound": "hbm", "kernel": "gather_mean_rows_kernel / gather_mean_sliced* (layer-1 gather-mean)" if split
             else "layer_fused_kernel (layer 1: gather-mean + W1 contraction)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
-            "traffic": traffic, "bytes_per_launch": round(l1),
+            "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": round(l1),
             "bytes_note": "SURVEY 8(d) compulsory bytes of the kernel's work (unique raw rows + sampled ids + counts); its own write of "
                           "the [|S1|, D0] means (a round trip the split layer adds) is excluded here and included in bytes_per_launch_own",
             "bytes_per_launch_own": round(own),
@@ -516,6 +546,8 @@ def main():
                 mj = json.load(open(mfile))
                 if mj.get("workload", workload) == workload:
                     roofline["mfma"] = mj.get("kernels")
+                    roofline["mfma_source"] = ("profiles/mfma.json <- " + str(mj.get("source")) + " (builder's rocprofv3 --pmc pass, "
+                                               "committed; not collected by this run)")
             except Exception:
                 pass
 
@@ -548,6 +580,17 @@ def main():
     else:
         was_pipe = pipe is not None
 
+    # ---- BASELINE configs[3] as a variant of every N > 1 line: the scaling curve's own workload, same K / W, same
+    #      fences and max-over-ranks; never substituted for `value` ----
+    if args.scale_variant == "on" or (args.scale_variant == "auto" and world > 1 and args.config == 3):
+        pipe = None
+        base = None
+        engines, outs = [], []
+        torch.cuda.empty_cache()
+        sv = scaling_variant(args, rank, world, dev, dist, fence)
+        if rank == 0:
+            variants = dict(variants or {}, configs3_rmat23=sv)
+
     # ---- CPU side by side: the reference-faithful restatement on this box's host cores ----
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -576,7 +619,7 @@ def main():
                        "batches_per_replay": bpr if exec_mode == "replay" else 1,
                        "variants": variants,
                        "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
-            "parity_max_err_vs_fp64_oracle": parity_err,
+            "parity_max_err_vs_fp64_oracle": parity_err, "timed_path_check": timed_check,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
@@ -586,6 +629,65 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scaling_variant(args, rank, world, dev, dist, fence):
+    """K steps of the role pipeline on BASELINE configs[3] (R-MAT 2^23 nodes / 128 M edges, D0 = 256, H = 128/128, fanout 15/25,
+    B = 4096 seeds per GPU): replicated graph + table (8.6 GB + 1.1 GB per GPU), every rank its own seed batches, no forward
+    collective; warm-up, fences and max-over-ranks as the headline run.  -> dict for config.variants (rank 0) / None."""
+    from sage355.engine import RolePipeline
+    from sage355.graph import rmat_graph
+    P = PRESETS[4]
+    if rank == 0:
+        graph = rmat_graph(P["scale"], P["edges"], seed=0, cache_dir=CACHE_DIR)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        graph = rmat_graph(P["scale"], P["edges"], seed=0, cache_dir=CACHE_DIR)
+    n, d0, h1, h2, k1, k2, b = graph.num_nodes, P["dim"], P["hidden1"], P["hidden"], P["k1"], P["k2"], P["batch"]
+    concat = args.mode == "concat"
+    mult = 2 if concat else 1
+    gen = torch.Generator(device=dev).manual_seed(0)
+    table = torch.randn(n, d0, generator=gen, device=dev)
+    wgen = torch.Generator().manual_seed(0)
+    w1 = ((torch.rand(h1, mult * d0, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h1 + mult * d0))).to(dev)
+    w2 = ((torch.rand(h2, mult * h1, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h2 + mult * h1))).to(dev)
+    rowptr, col = graph.to(dev)
+    candidates = np.nonzero(graph.degrees() > 0)[0]
+    total = args.warmup + args.steps
+    rs = np.random.default_rng(1 + 7919 * rank)
+    seeds = torch.from_numpy(np.stack([rs.choice(candidates, b, replace=False) for _ in range(total)]).astype(np.int32)).to(dev)
+    keys = [0x5A6E355 + 1000003 * rank + i for i in range(total)]
+    relabel = "degree" if args.engine_layout == "degree" else None
+    pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, concat=concat,
+                        agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel)
+    out = torch.empty(max(args.depth, 4), b, h2, device=dev)
+    torch.cuda.synchronize()
+    t_ph = time.perf_counter()
+    while time.perf_counter() - t_ph < min(args.preheat_seconds, 0.3):
+        pipe.submit_many(seeds[:min(total, 8)], keys[:min(total, 8)], out)
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        pipe.submit(seeds[i], keys[i], out[i % out.shape[0]])
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        pipe.submit(seeds[i], keys[i], out[i % out.shape[0]])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    del pipe
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    return {"value": round(world * b * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 5), "n_gpus": world,
+            "workload": f"BASELINE configs[3]: R-MAT 2^{P['scale']} / {P['edges']} edges ({n} nodes), {graph.nnz} directed nnz, {d0}-dim fp32 "
+                        f"features, {args.mode} encoder H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU, role pipeline depth {args.depth}",
+            "note": "the workload BASELINE names for the 1/2/4/8 curve; same steps / warm-up / fences / max-over-ranks as `value`, which "
+                    "stays on configs[2]"}
 
 
 def cpu_port_baseline(graph, table, w1, w2, candidates, k1, k2, concat, budget_s):

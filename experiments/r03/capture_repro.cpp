@@ -14,6 +14,22 @@
 //   5  pattern 1 with hipEventDisableSystemFence events
 //   6  pattern 2, batches = depth (no event re-recorded, but the wait S(b) <- L(b - depth) never appears)
 //   7  pattern 1, relaxed capture mode (hipStreamCaptureModeRelaxed) instead of global
+// Second series (after 1-5 and 7 crashed inside hipStreamEndCapture while 0 and 6 passed): what separates 6 from 1?
+//   8  pattern 1 WITHOUT the workspace-release wait S(b) <- L(b - depth)    (same 40 kernels: is it the graph's size?)
+//   9  pattern 1, batches = depth + 1                                        (exactly one S <- L wait)
+//  10  two forked streams A, B: A: k, e1 | B: wait e1, k, e2 | A: wait e2, k | origin joins both   (minimal "wait back" between
+//      two forked streams)
+//  11  the same with A = the origin stream                                   (the shape of a fork + join, which pattern 6 has too)
+//  12  pattern 10, but B's event is also waited for by the origin BEFORE A waits for it
+// Third series (8 passed, 9 crashed, 10-12 passed): in 9 the event S waits for, L(0)'s, is no longer the TAIL of stream L's
+// captured work (L(1) .. L(3) were enqueued after it); every other wait of every pattern targets the producer's tail.
+//  13  two forked streams: A: k1, record e1, k2 | B: wait e1, k        (minimal wait on an INTERIOR event)
+//  14  pattern 9, the release relayed through a helper stream: right after L(b) is recorded a fresh stream H_b waits for it and
+//      records h_b (H_b gets no more work, so h_b stays its tail); S(b + depth) waits for h_b
+//  15  pattern 9, the release edge without an event: hipStreamGetCaptureInfo_v2 on stream L right after L(b) gives its node;
+//      before S(b + depth), hipStreamUpdateCaptureDependencies(S, {that node}, add)
+//  16  pattern 1 (8 batches) with the relay of 14
+//  17  pattern 1 (8 batches) with the explicit dependency of 15
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,15 +85,59 @@ static int run(int pattern) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int expect = 0;
-    if (pattern == 0) {
+    if (pattern == 13) {
+        hipEvent_t f, e1, e3, e4;
+        for (hipEvent_t* e : {&f, &e1, &e3, &e4}) CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        hipStream_t A = st[0], B = st[1];
+        CK(hipStreamBeginCapture(origin, mode));
+        CK(hipEventRecord(f, origin));
+        CK(hipStreamWaitEvent(A, f, 0));
+        CK(hipStreamWaitEvent(B, f, 0));
+        hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, A, d, 1); ++expect;
+        CK(hipEventRecord(e1, A));
+        hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, A, d, 1); ++expect;      // A moves on: e1 is now interior
+        CK(hipStreamWaitEvent(B, e1, 0));
+        hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, B, d, 1); ++expect;
+        CK(hipEventRecord(e3, A)); CK(hipStreamWaitEvent(origin, e3, 0));
+        CK(hipEventRecord(e4, B)); CK(hipStreamWaitEvent(origin, e4, 0));
+        printf("  end capture ...\n"); fflush(stdout);
+        CK(hipStreamEndCapture(origin, &graph));
+    } else if (pattern >= 10 && pattern <= 12) {
+        hipEvent_t f, e1, e2, e3, e4;
+        for (hipEvent_t* e : {&f, &e1, &e2, &e3, &e4}) CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        hipStream_t A = pattern == 11 ? origin : st[0], B = st[1];
+        CK(hipStreamBeginCapture(origin, mode));
+        CK(hipEventRecord(f, origin));
+        if (A != origin) CK(hipStreamWaitEvent(A, f, 0));
+        CK(hipStreamWaitEvent(B, f, 0));
+        hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, A, d, 1); ++expect;
+        CK(hipEventRecord(e1, A));
+        CK(hipStreamWaitEvent(B, e1, 0));
+        hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, B, d, 1); ++expect;
+        CK(hipEventRecord(e2, B));
+        if (pattern == 12) CK(hipStreamWaitEvent(origin, e2, 0));
+        CK(hipStreamWaitEvent(A, e2, 0));
+        hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, A, d, 1); ++expect;
+        if (A != origin) { CK(hipEventRecord(e3, A)); CK(hipStreamWaitEvent(origin, e3, 0)); }
+        CK(hipEventRecord(e4, B));
+        CK(hipStreamWaitEvent(origin, e4, 0));
+        printf("  end capture ...\n"); fflush(stdout);
+        CK(hipStreamEndCapture(origin, &graph));
+    } else if (pattern == 0) {
         CK(hipStreamBeginCapture(origin, mode));
         for (int i = 0; i < 20; ++i) { hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, origin, d, 1); ++expect; }
         printf("  end capture ...\n"); fflush(stdout);
         CK(hipStreamEndCapture(origin, &graph));
     } else {
-        const bool fresh = pattern == 1 || pattern == 3 || pattern == 5 || pattern == 7;
+        const bool fresh = pattern == 1 || pattern == 3 || pattern == 5 || pattern >= 7;   // 14-17 too
         const unsigned flags = (pattern == 4 || pattern == 5) ? (hipEventDisableTiming | hipEventDisableSystemFence) : hipEventDisableTiming;
-        const int depth = 4, batches = pattern == 6 ? depth : 8;
+        const int depth = 4, batches = pattern == 6 ? depth : (pattern == 9 || pattern == 14 || pattern == 15) ? depth + 1 : 8;
+        const bool release_wait = pattern != 8;
+        const bool relay = pattern == 14 || pattern == 16, explicit_dep = pattern == 15 || pattern == 17;
+        hipEvent_t relay_ev[8];
+        hipStream_t relay_st[8];
+        hipGraphNode_t lnode[8];
+        for (int i = 0; i < 8; ++i) { relay_ev[i] = nullptr; relay_st[i] = nullptr; lnode[i] = nullptr; }
         Events ev;
         if (int rc = ev.init(flags, fresh)) return rc;
         hipEvent_t fork_ev;
@@ -89,13 +149,33 @@ static int run(int pattern) {
             const int slot = b % depth;
             for (int r = 0; r < 4; ++r) {
                 // consumer waits on producer: S <- L of the slot's previous batch, G <- S, D <- G, L <- D
-                if (r == 0) { if (b >= depth) CK(hipStreamWaitEvent(st[0], ev.last[3][slot], 0)); }
+                if (r == 0) {
+                    if (b >= depth && release_wait) {
+                        if (relay) CK(hipStreamWaitEvent(st[0], relay_ev[b - depth], 0));
+                        else if (explicit_dep) CK(hipStreamUpdateCaptureDependencies(st[0], &lnode[b - depth], 1, hipStreamAddCaptureDependencies));
+                        else CK(hipStreamWaitEvent(st[0], ev.last[3][slot], 0));
+                    }
+                }
                 else CK(hipStreamWaitEvent(st[r], ev.last[r - 1][slot], 0));
                 hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, st[r], d, 1); ++expect;
                 if (r == 0) { hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, st[r], d, 1); ++expect; }     // two sampler kernels
                 if (int rc = ev.record(r, slot, st[r])) return rc;
+                if (r == 3 && relay && b + depth < batches) {          // L(b) is the tail of stream L right now
+                    CK(hipStreamCreateWithFlags(&relay_st[b], hipStreamNonBlocking));
+                    CK(hipEventCreateWithFlags(&relay_ev[b], flags));
+                    CK(hipStreamWaitEvent(relay_st[b], ev.last[3][slot], 0));
+                    CK(hipEventRecord(relay_ev[b], relay_st[b]));
+                }
+                if (r == 3 && explicit_dep) {
+                    hipStreamCaptureStatus cs; unsigned long long id = 0; hipGraph_t g = nullptr; const hipGraphNode_t* deps = nullptr; size_t nd = 0;
+                    CK(hipStreamGetCaptureInfo_v2(st[3], &cs, &id, &g, &deps, &nd));
+                    if (nd != 1) { printf("  stream L has %zu tail nodes\n", nd); return 12; }
+                    lnode[b] = deps[0];
+                }
             }
         }
+        for (int i = 0; i < 8; ++i)                                     // helper streams join the origin too
+            if (relay_st[i]) CK(hipStreamWaitEvent(origin, relay_ev[i], 0));
         // join: the origin waits for every role stream's last work
         const int lslot = (batches - 1) % depth;
         for (int r = 0; r < 4; ++r) {
@@ -121,6 +201,6 @@ static int run(int pattern) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { printf("usage: capture_repro <pattern 0..7>   (experiments/r03/capture_repro.sh runs them all, one process each)\n"); return 2; }
+    if (argc < 2) { printf("usage: capture_repro <pattern 0..17>   (experiments/r03/capture_repro.sh runs them all, one process each)\n"); return 2; }
     return run(atoi(argv[1]));
 }

@@ -170,7 +170,7 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
 #endif
         (void)kForce;
         const int nslice = sage_cdiv(dim, sl * 4);
-        const int blocks = nslice * (kNumCU * sage_tunables().gather_blocks_per_cu / nslice);
+        const int blocks = nslice * max(1, kNumCU * sage_tunables().gather_blocks_per_cu / nslice);   // >= one block per slice (very wide rows)
         if (sage_tunables().gather_variant == 2) {
             // one destination row per lane group (see sage_gather_body.h)
             if (sl == 8) launch_rows<8>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice);

@@ -71,6 +71,38 @@ class _LinearAct(torch.autograd.Function):
         return grad_agg, grad_w, grad_self, None, None
 
 
+class _TwoHop(torch.autograd.Function):
+    """Two stacked Encoders (model.py:219-222) as ONE differentiable operator: forward = TwoHopEngine.forward (sage_forward2),
+    backward = TwoHopEngine.backward_weights on the intermediates that forward left in the engine's workspace.  Inputs are the
+    two `weight` Parameters (on any device: their gradients go back to where they live); the raw feature table is frozen
+    (model.py:214-215).  Output [B, h2] on the GPU."""
+
+    @staticmethod
+    def forward(ctx, w1, w2, engine, ids, key):
+        out = engine.forward(ids, seed=key)
+        ctx.engine, ctx.ids, ctx.key, ctx.generation = engine, ids, key, engine.generation
+        ctx.devices = (w1.device, w2.device)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e = ctx.engine
+        (out,) = ctx.saved_tensors
+        if e.generation != ctx.generation:
+            # another forward has used the workspace since (an evaluation between loss and backward): run this one again --
+            # the device sampler is a pure function of (key, node id), so the same sets, rows and h1 come back
+            out = e.forward(ctx.ids, seed=ctx.key)
+        g1, g2 = e.backward_weights(out, grad_out.to(out.device, torch.float32), need_w1=ctx.needs_input_grad[0])
+        g1 = g1.to(ctx.devices[0]) if (g1 is not None and ctx.needs_input_grad[0]) else None
+        g2 = g2.to(ctx.devices[1]) if ctx.needs_input_grad[1] else None
+        return g1, g2, None, None, None
+
+
+def two_hop(w1, w2, engine, ids, key):
+    return _TwoHop.apply(w1, w2, engine, ids, key)
+
+
 def gather_mean(table, nbr, cnt, any_nonempty=None, slot_rows=None, self_row=None):
     if torch.is_grad_enabled() and table.requires_grad:
         return _GatherMean.apply(table, nbr, cnt, any_nonempty, slot_rows, self_row)

@@ -45,14 +45,19 @@ from .graph import csr_from_adj_lists
 SIGMOID_INITIALIZERS = ("node_degree", "shared", "pagerank")   # encoders.py:58
 
 _CSR_CACHE_MAX = 8            # adjacency objects kept (LRU): both layers of a model share one, a process holds a few models
-_CSR_CHECK_MAX_NODES = 200_000  # adjacencies up to this many keys are re-fingerprinted on every call
+_CSR_CHECK_MAX_NODES = 200_000  # adjacencies up to this many keys are re-fingerprinted (periodically, below); larger ones are frozen
 _csr_cache = collections.OrderedDict()
 
 
+_CSR_RECHECK_EVERY = 64       # forwards between two full fingerprints of a cached adjacency
+
+
 def _fingerprint(adj_lists):
-    """(non-empty sets, total degree): detects an adjacency mutated in place after first use.  Empty sets that the
-    reference's defaultdict inserts on a miss (encoders.py:47) do not change it.  O(N) in Python, so only computed for
-    small adjacencies; a large one is FROZEN at first use (call invalidate_adjacency(adj_lists) after editing it)."""
+    """(non-empty sets, total degree, content hash of a sample of rows): detects an adjacency mutated in place after first
+    use, including an edge MOVED between two sampled rows.  Empty sets that the reference's defaultdict inserts on a miss
+    (encoders.py:47) do not change it.  O(N) in Python, so it is recomputed only every _CSR_RECHECK_EVERY-th call per
+    adjacency, and never for a large one, which is FROZEN at first use: call invalidate_adjacency(adj_lists) after editing
+    an adjacency that a sage355 Encoder has already seen."""
     if len(adj_lists) > _CSR_CHECK_MAX_NODES:
         return None
     nonempty = total = 0
@@ -60,7 +65,13 @@ def _fingerprint(adj_lists):
         n = len(s)
         total += n
         nonempty += n > 0
-    return nonempty, total
+    stride, i, h = max(1, nonempty // 256), 0, 0
+    for k, s in adj_lists.items():               # ~256 of the NON-EMPTY rows, evenly spaced (empty ones come and go, see above)
+        if s:
+            if i % stride == 0:
+                h = (h * 1000003 + hash(k) + 31 * sum(s)) & 0xFFFFFFFFFFFF
+            i += 1
+    return nonempty, total, h
 
 
 def invalidate_adjacency(adj_lists=None):
@@ -75,11 +86,21 @@ def _device_csr(adj_lists, num_nodes_hint, device):
     """dict-of-sets -> CSR in HBM, cached per adjacency object (both layers share one, model.py:219-222).
     The reference re-reads the dict on every call; here the conversion is cached and revalidated by a fingerprint."""
     key = id(adj_lists)
-    fp = _fingerprint(adj_lists)
     hit = _csr_cache.get(key)
-    if hit is not None and hit[0] is adj_lists and hit[3] == fp and hit[4] == num_nodes_hint:
-        _csr_cache.move_to_end(key)
-        return hit[1], hit[2]
+    if hit is not None and hit[0] is adj_lists and hit[4] == num_nodes_hint:
+        # every call: O(1) -- a changed key count (new nodes; also the empty sets the reference's defaultdict inserts on a miss)
+        # triggers the full fingerprint at once; otherwise it is recomputed every _CSR_RECHECK_EVERY-th call (it walks every
+        # set in Python: ~0.3 ms at Cora's size, twice per forward, was a third of a 256-seed training step)
+        state = hit[5]
+        state[0] += 1
+        if len(adj_lists) == state[1] and state[0] % _CSR_RECHECK_EVERY != 0:
+            _csr_cache.move_to_end(key)
+            return hit[1], hit[2]
+        if hit[3] == _fingerprint(adj_lists):
+            state[1] = len(adj_lists)
+            _csr_cache.move_to_end(key)
+            return hit[1], hit[2]
+    fp = _fingerprint(adj_lists)
     g = csr_from_adj_lists(adj_lists, None)
     if num_nodes_hint and g.num_nodes < num_nodes_hint:
         pad = np.full(num_nodes_hint - g.num_nodes, g.rowptr[-1], dtype=np.int64)
@@ -88,7 +109,7 @@ def _device_csr(adj_lists, num_nodes_hint, device):
     rowptr, col = g.to(device)
     if col.numel() == 0:
         col = torch.zeros(1, dtype=torch.int32, device=device)
-    _csr_cache[key] = (adj_lists, rowptr, col, fp, num_nodes_hint)
+    _csr_cache[key] = (adj_lists, rowptr, col, fp, num_nodes_hint, [0, len(adj_lists)])
     _csr_cache.move_to_end(key)
     while len(_csr_cache) > _CSR_CACHE_MAX:
         _csr_cache.popitem(last=False)
@@ -166,8 +187,8 @@ class Encoder(nn.Module):
             raise native.SageError("sage355.Encoder needs an MI355X; there is no CPU path")
         native.lib()
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self._can_fuse_two_hop() and not training:
-            out = self._forward_two_hop(nodes)
+        if self._can_fuse_two_hop():
+            out = self._forward_two_hop(nodes, training)
         elif self._is_table() and self.num_sample is not None and self.num_sample <= native.MAX_FANOUT \
                 and isinstance(self.aggregator, MeanAggregator):
             out = self._forward_table(nodes)
@@ -176,14 +197,39 @@ class Encoder(nn.Module):
         out = out.t()
         return out if self.cuda else out.cpu()
 
-    def _forward_two_hop(self, nodes):
+    def _engine_weight(self, tag):
+        """The device tensor the engine reads this Encoder's weight from: the Parameter's own storage when it lives on the GPU
+        (an in-place optimizer step is then seen as it is), else a persistent device buffer refreshed from the host Parameter
+        (strict drop-in mode, cuda=False: model.py keeps the model on the host).  -> (tensor, refreshed)"""
+        w = self.weight
+        if w.is_cuda:
+            hit = self._dev_cache.get(tag)
+            if hit is None or hit[0] != w.data_ptr():
+                hit = (w.data_ptr(), w.detach())          # shares storage AND version counter with the Parameter
+                self._dev_cache[tag] = hit
+            return hit[1], False
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._dev_cache.get(tag)
+        if hit is None or hit[1].shape != w.shape:
+            hit = [None, torch.empty(w.shape, dtype=torch.float32, device="cuda")]
+            self._dev_cache[tag] = hit
+        refreshed = hit[0] != key or torch.is_grad_enabled()   # while training, never trust the key: `.data` writes do not move it
+        if refreshed:
+            hit[1].copy_(w.detach(), non_blocking=True)
+            hit[0] = key
+        return hit[1], refreshed
+
+    def _forward_two_hop(self, nodes, training=False):
+        """Both layers as one C call (sage_forward2).  Under grad mode the same call is one autograd node (autograd._TwoHop)
+        whose backward runs the C-ABI backward kernels on the engine's intermediates: the reference's training loop
+        (model.py:240-252) then runs at the engine's speed through the unchanged class surface."""
         base = self.base_model
         dev = torch.device("cuda")
         table = base._on_device(base.features.weight, "table")
         n = table.shape[0]
         rp1, c1 = _device_csr(base.adj_lists, n, dev)
-        rp2, c2 = _device_csr(self.adj_lists, n, dev)
-        w1, w2 = base._weight_dev().detach(), self._weight_dev().detach()
+        rp2, c2 = (rp1, c1) if self.adj_lists is base.adj_lists else _device_csr(self.adj_lists, n, dev)
+        (w1, r1), (w2, r2) = base._engine_weight("engine_w"), self._engine_weight("engine_w")
         key = (rp1.data_ptr(), rp2.data_ptr(), table.data_ptr(), w1.data_ptr(), w2.data_ptr(), base.num_sample,
                self.num_sample, self.gcn, self._agg_self_loop(), base._act(), self._act())
         if self._engine is None or self._engine_key != key:
@@ -191,7 +237,13 @@ class Encoder(nn.Module):
                                         agg_self_loop=self._agg_self_loop(), act1=base._act(), act2=self._act(),
                                         nan_empty=True, max_batch=max(len(nodes), 256), rowptr_outer=rp2, col_outer=c2)
             self._engine_key = key
-        return self._engine.forward(nodes, seed=random.getrandbits(64))
+        elif r1 or r2:
+            self._engine.invalidate_weights()             # the buffers were rewritten in place: planes / padded copies are stale
+        sampler_key = random.getrandbits(64)
+        if training:
+            ids = ops.as_ids(nodes, dev, n)
+            return autograd.two_hop(base.weight, self.weight, self._engine, ids, sampler_key)
+        return self._engine.forward(nodes, seed=sampler_key)
 
     def _forward_table(self, nodes):
         """One layer over a raw feature table (encoders.py:47-62 with features = nn.Embedding)."""

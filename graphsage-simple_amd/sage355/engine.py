@@ -79,6 +79,8 @@ class TwoHopEngine:
         self._cursor = None
         self._graph = None
         self._last_batch = 0
+        self.generation = 0                  # forwards run so far: a backward checks that the workspace still holds ITS forward
+        self._bwd = None                     # scratch of backward_weights (allocated on first use)
         self._reserve(max_batch)
 
     def _relabel_by_degree(self):
@@ -141,6 +143,12 @@ class TwoHopEngine:
                     self._w2p[:, c * self.h1p: c * self.h1p + self.h1] = self.w2[:, c * self.h1: (c + 1) * self.h1]
             self._wpad_key = key
         return self._w1p, self._w2p
+
+    def invalidate_weights(self):
+        """Forget every cached form of the weights (zero-padded copies, bf16 planes, the C model struct): the next forward
+        rebuilds them from the tensors as they are NOW.  The caches are keyed on (data_ptr, tensor._version), which does not move
+        when the weights are written through `.data`, by a collective, or by a replayed hipGraph."""
+        self._w1prep_key = self._wpad_key = self._model_key = None
 
     def refresh_weights(self):
         """Re-read the caller's weights into the padded copies (only needed between replays of a captured graph when
@@ -223,6 +231,7 @@ class TwoHopEngine:
         if rc != 0:
             native.check(rc, "forward2 (queued)")
         self._last_batch = self._queue_batch
+        self.generation += 1
         return out
 
     def capture(self, out=None, batches=1):
@@ -300,7 +309,80 @@ class TwoHopEngine:
                 # block is what cleans up): give the next call a clean workspace rather than a full hash table
                 L.sage_forward2_init(args[0], self.workspace.data_ptr(), self.workspace.numel(), self.max_batch, args[-1])
         self._last_batch = b
+        self.generation += 1
         return out
+
+    # ---- backward of the last forward through the intermediates it left in the workspace (model.py:249) ----
+    def backward_weights(self, out, grad_out, need_w1=True):
+        """Gradients of (w1, w2), in the caller's shapes, of the LAST forward on this engine: `out` is what it returned
+        ([B, h2]), grad_out = d loss / d out.  Autograd of the reference's expression (mm / relu / cat / div) from
+        the engine's own intermediates -- nbr / cnt / row2 / h1 (and the layer-1 means when layer 1 ran split) are still in the
+        workspace, the layer-2 means are re-gathered -- with the C-ABI backward kernels.  The table is frozen (model.py:214-215):
+        no gradient reaches it.  No host synchronisation: the frontier size never leaves the device."""
+        from . import ops
+        lib = native.lib()
+        st = native.stream_handle()
+        P = native.ptr
+        L, b = self.layout, self._last_batch
+        dev = self.device
+        if self._bwd is None or self._bwd["max_s1"] != L.max_s1:
+            self._bwd = {"max_s1": L.max_s1, "nlive": torch.zeros(1, dtype=torch.int32, device=dev),
+                         "grad_h1": torch.zeros(L.max_s1, self.h1p, device=dev), "agg1": None,
+                         "any": torch.ones(1, dtype=torch.int32, device=dev)}
+        sc = self._bwd
+        first = b if self.concat else 0
+        k1, k2, h1p, d0p = self.k1, self.k2, self.h1p, self.d0p
+        # rows of layer 1 = first + frontier size, kept on the device (counters[8] is the read-back copy the forward's last block leaves)
+        torch.add(self._view(L.counters, 16, torch.int32)[8:9], first, out=sc["nlive"])
+        grad_out = grad_out.contiguous()
+        w1p, w2p = self._weights()
+        h1 = self._view(L.h1, L.max_s1 * h1p, torch.float32).view(L.max_s1, h1p)
+        row2 = self._view(L.row2, b * k2, torch.int32).view(b, k2)
+        cnt2 = self._view(L.cnt2, b, torch.int32)
+        self_row2 = self._view(L.self_row2, b, torch.int32) if self.agg_self_loop else None
+        nbr1 = self._view(L.nbr1, L.max_s1 * k1, torch.int32).view(L.max_s1, k1)
+        cnt1 = self._view(L.cnt1, L.max_s1, torch.int32)
+        s1_nodes = self._view(L.s1_nodes, L.max_s1, torch.int32)
+        # ---- layer 2 backward: agg2 is recomputed (one small gather), then dW2 and d[h1_self | agg2]
+        agg2 = ops.gather_mean(h1, row2, cnt2, self_row=self_row2, any_nonempty=sc["any"])
+        mult = 2 if self.concat else 1
+        g_w2p = torch.zeros_like(w2p)
+        g_x2 = torch.empty(b, mult * h1p, device=dev)
+        native.check(lib.sage_linear_act_backward(P(h1) if self.concat else None, h1p, None, P(agg2), agg2.stride(0), h1p, P(w2p),
+                                                  w2p.stride(0), self.h2, self.act2, P(out), out.stride(0), P(grad_out), grad_out.stride(0), b, None,
+                                                  P(g_w2p), g_w2p.stride(0), P(g_x2) if need_w1 else None, g_x2.stride(0), st),
+                     "linear_act_backward (layer 2)")
+        g_w1p = None
+        if need_w1:
+            # ---- d h1: the means scatter back to the frontier rows, the concat encoder's own rows are the first B
+            sc["grad_h1"].zero_()
+            g_agg2 = g_x2[:, (mult - 1) * h1p:]
+            native.check(lib.sage_gather_mean_backward(P(g_agg2), g_x2.stride(0), h1p, P(row2), P(cnt2), k2, b, None, None, P(self_row2),
+                                                       P(sc["grad_h1"]), L.max_s1, h1p, st), "gather_mean_backward (layer 2)")
+            if self.concat:
+                sc["grad_h1"][:b] += g_x2[:, :h1p]
+            # ---- layer 1 backward: only dW1 (the table is frozen); agg1 from the workspace (split layer) or recomputed on the live rows
+            self_row1 = s1_nodes if self.agg_self_loop else None
+            if L.layer1_split:
+                # the split layer (sliced gather + contraction) left the means of this very forward in the workspace: no second gather
+                agg1 = self._view(L.agg1, L.max_s1 * d0p, torch.float32).view(L.max_s1, d0p)
+            else:
+                if sc["agg1"] is None:
+                    sc["agg1"] = torch.zeros(L.max_s1, d0p, device=dev)
+                ops.gather_mean(self.table, nbr1, cnt1, self_row=self_row1, any_nonempty=sc["any"], n_dev=sc["nlive"], out=sc["agg1"])
+                agg1 = sc["agg1"]
+            g_w1p = torch.zeros_like(w1p)
+            native.check(lib.sage_linear_act_backward(P(self.table) if self.concat else None, self.table_ld, P(s1_nodes) if self.concat else None,
+                                                      P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, self.act1, P(h1), h1p,
+                                                      P(sc["grad_h1"]), h1p, L.max_s1, P(sc["nlive"]), P(g_w1p), g_w1p.stride(0), None, 0, st),
+                         "linear_act_backward (layer 1)")
+        # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
+        if self._padded:
+            g_w1 = None if g_w1p is None else torch.cat([g_w1p[:self.h1, c * d0p: c * d0p + self.d0] for c in range(mult)], 1)
+            g_w2 = torch.cat([g_w2p[:, c * h1p: c * h1p + self.h1] for c in range(mult)], 1)
+        else:
+            g_w1, g_w2 = g_w1p, g_w2p
+        return g_w1, g_w2
 
     # ---- read-back of the last forward's intermediates (tests, parity gate, byte counting) ----
     def _view(self, off, count, dtype):
@@ -418,7 +500,7 @@ class RolePipeline:
         rc = native.lib().sage_pipe_submit_profiled(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(),
                                                     out.stride(0), gather_events)
         if rc != 0:
-            self._broken = True
+            self._broken = rc == native.ELAUNCH
             native.check(rc, "pipe_submit_profiled")
 
     def submit(self, seeds, key, out):
@@ -433,7 +515,7 @@ class RolePipeline:
         self._sync_weights()
         rc = native.lib().sage_pipe_submit(self._h, seeds.data_ptr(), int(key) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), out.stride(0))
         if rc != 0:
-            self._broken = True
+            self._broken = rc == native.ELAUNCH      # argument errors are raised before anything is enqueued: the pipe stays usable
             native.check(rc, "pipe_submit")
 
     def submit_many(self, seeds, keys, out, segment_start=False):
@@ -447,7 +529,7 @@ class RolePipeline:
         if len(keys) != n:
             raise native.SageError("RolePipeline.submit_many: one sampler key per batch")
         if (out.dim() != 3 or out.shape[1:] != (self.batch, self.h2) or out.dtype != torch.float32 or not out.is_cuda
-                or not out.is_contiguous() or out.shape[0] < min(self.depth, n)):
+                or not out.is_contiguous() or out.shape[0] < self.depth):
             raise native.SageError("RolePipeline.submit_many: `out` must be a contiguous [slots >= depth, batch, h2] fp32 device tensor")
         self._sync_weights()
         karr = (ctypes.c_uint64 * n)(*[int(k) & 0xFFFFFFFFFFFFFFFF for k in keys])
@@ -455,7 +537,7 @@ class RolePipeline:
         rc = native.lib().sage_pipe_submit_many(self._h, seeds.data_ptr(), self.batch, karr, n, out.data_ptr(), out.stride(1),
                                                 out.stride(0), out.shape[0], 1 if segment_start else 0)
         if rc != 0:
-            self._broken = True
+            self._broken = rc == native.ELAUNCH
             native.check(rc, "pipe_submit_many")
 
     def synchronize(self):

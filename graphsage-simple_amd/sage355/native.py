@@ -16,6 +16,7 @@ ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
 TAG_INNER, TAG_OUTER, TAG_INNER_SELF = 1, 2, 3
 MAX_FANOUT = 64
 ABI_VERSION = 2
+EINVAL, EUNSUPPORTED, ELAUNCH, ENOSPACE = -1, -2, -3, -4      # include/sage355.h
 
 # every symbol include/sage355.h declares (tests check the library exports each one)
 SYMBOLS = [

@@ -5,11 +5,12 @@ Kept from the reference: the classifier (weight [C, embed_dim], xavier, scores =
 CrossEntropyLoss), the 10 / 10 / 80 test / val / train split of np.random.permutation
 (model.py:229-234), SGD lr = 0.7 (model.py:237), random.shuffle of the train list per epoch,
 micro/macro F1 on the validation split (model.py:256-258), mean batch time (model.py:259).
-The per-epoch shuffle draws from a generator of its OWN (`random.Random(seed)`), not from Python's
-global `random`: the neighbour samplers consume the global stream by a shard-dependent amount, so
-data-parallel ranks sharing it would hold different permutations of `train` and `shard_batch` would
-slice overlapping / incomplete shards.  With a private generator every rank holds the same
-permutation and the union of the shards is exactly the global batch.
+Single process: the per-epoch shuffle is `random.shuffle(train)` on Python's GLOBAL stream, the one the strict
+path's neighbour sampling also draws from -- as model.py:243 -- so a strict run consumes `random` call for
+call like the reference.  Data parallel (world_size > 1): the shuffle draws from a generator of its OWN
+(`random.Random(seed)`), because the samplers consume the global stream by a shard-dependent amount and ranks
+sharing it would hold different permutations of `train`: `shard_batch` would slice overlapping / incomplete
+shards.  With the private generator every rank holds the same permutation and the shards tile the global batch.
 Deliberately different: batches are plain `batch_size` slices by default; `ref_batching=True`
 reproduces the reference's `train[batch:max(train_num, batch+batch_size)]` descending batches
 (model.py:244, a `max` where `min` was meant).  Everything stays on the GPU; with world_size > 1
@@ -68,7 +69,8 @@ def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, ba
                  model=None, verbose=True, sample_seed=None, return_model=False, on_batch=None, **model_kwargs):
     """-> dict(f1_micro, f1_macro, mean_batch_time, losses).  Mirrors run_model (model.py:184-259).
     `seed` seeds numpy (the split) and Python's random (shuffles + neighbour sampling) as model.py:192-193
-    does; `sample_seed` reseeds only Python's random, to vary the sampling stream on a fixed split."""
+    does; `sample_seed` reseeds only Python's random, to vary the sampling stream on a fixed split.  With
+    world_size > 1 the shuffles come from a private `random.Random(seed)` instead (module docstring)."""
     from sklearn.metrics import f1_score
     np.random.seed(seed)
     random.seed(seed if sample_seed is None else sample_seed)
@@ -83,7 +85,8 @@ def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, ba
     val = rand_indices[int(0.1 * num_nodes):int(0.2 * num_nodes)]
     train = list(rand_indices[int(0.2 * num_nodes):])
     optimizer = torch.optim.SGD(params, lr=lr)
-    shuffler = random.Random(seed)        # identical on every rank, untouched by neighbour sampling
+    # world 1: the global stream, as model.py:243; world > 1: a generator identical on every rank, untouched by neighbour sampling
+    shuffler = random if world == 1 else random.Random(seed)
     labels_t = torch.as_tensor(labels, dtype=torch.int64).squeeze(-1)
     times, losses = [], []
     for _ in range(epochs):
@@ -149,16 +152,14 @@ class EngineTrainer:
             init.xavier_uniform_(w)
         self.lr = float(lr)
         self.concat = not gcn
+        # data parallel: every rank starts from rank 0's weights.  BEFORE the engine is built: its constructor prepares the bf16
+        # planes of W1 (and zero-padded copies of odd widths) and caches them under (data_ptr, _version), which a broadcast
+        # through `.data` does not move -- ranks != 0 would run their first step on planes of their own initial W1
+        dist.broadcast_params(self.parameters())
         self.engine = TwoHopEngine(rowptr, col, table, self.w1, self.w2, num_sample1, num_sample2, concat=self.concat,
                                    agg_self_loop=agg_self_loop, max_batch=max_batch, relabel=relabel)
+        self.engine.invalidate_weights()
         self._native, self._ops = native, ops
-        e = self.engine
-        L = e.layout
-        dist.broadcast_params(self.parameters())             # data parallel: every rank starts from rank 0's weights
-        self._nlive = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=dev)
-        self._agg1 = torch.zeros(L.max_s1, e.d0p, device=dev)
-        self._any = torch.ones(1, dtype=torch.int32, device=dev)
         self._out_q = None
         self._step_graph = None
 
@@ -176,9 +177,7 @@ class EngineTrainer:
         """loss (device scalar) and the gradients of (w1, w2, w_cls) for one batch; nothing is updated.
         global_batch: data parallel -- this rank holds a shard of a mini-batch of that many seeds; its loss is the SUM over its
         shard / global_batch, so that the SUM of the ranks' gradients is the full-batch gradient."""
-        native, ops, e = self._native, self._ops, self.engine
-        lib = native.lib()
-        st = native.stream_handle()
+        e = self.engine
         if seeds is None:                                                  # the batch at the engine's queue cursor (capturable step)
             b = e._queue_batch
             if self._out_q is None or self._out_q.shape[0] != b:
@@ -187,14 +186,6 @@ class EngineTrainer:
         else:
             b = seeds.shape[0]
             out = e.forward(seeds, seed=key)                               # sample, frontier, sample, layer 1, layer 2
-        L = e.layout
-        if L.max_s1 != self._grad_h1.shape[0]:                             # the engine re-reserved for a bigger batch
-            self._grad_h1 = torch.zeros(L.max_s1, e.h1p, device=out.device)
-            self._agg1 = torch.zeros(L.max_s1, e.d0p, device=out.device)
-        first = b if self.concat else 0
-        k1, k2, h1p, d0p = e.k1, e.k2, e.h1p, e.d0p
-        # rows of layer 1 = first + frontier size, kept on the device (counters[8] is the read-back copy the forward's last block leaves)
-        torch.add(e._view(L.counters, 16, torch.int32)[8:9], first, out=self._nlive)
         # classifier + loss + their gradients: stock torch on the same stream (model.py:59-69)
         emb = out.detach().requires_grad_(True)
         w_cls = self.w_cls.detach().requires_grad_(True)
@@ -203,50 +194,8 @@ class EngineTrainer:
         else:
             loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels, reduction="sum") / float(global_batch)
         g_out, g_cls = torch.autograd.grad(loss, (emb, w_cls))
-        g_out = g_out.contiguous()
-        w1p, w2p = e._weights()
-        h1 = e._view(L.h1, L.max_s1 * h1p, torch.float32).view(L.max_s1, h1p)
-        row2 = e._view(L.row2, b * k2, torch.int32).view(b, k2)
-        cnt2 = e._view(L.cnt2, b, torch.int32)
-        self_row2 = e._view(L.self_row2, b, torch.int32) if e.agg_self_loop else None
-        nbr1 = e._view(L.nbr1, L.max_s1 * k1, torch.int32).view(L.max_s1, k1)
-        cnt1 = e._view(L.cnt1, L.max_s1, torch.int32)
-        s1_nodes = e._view(L.s1_nodes, L.max_s1, torch.int32)
-        P = native.ptr
-        # ---- layer 2 backward: agg2 is recomputed (one small gather), then dW2 and d[h1_self | agg2]
-        agg2 = ops.gather_mean(h1, row2, cnt2, self_row=self_row2, any_nonempty=self._any)
-        mult = 2 if self.concat else 1
-        g_w2p = torch.zeros_like(w2p)
-        g_x2 = torch.empty(b, mult * h1p, device=out.device)
-        native.check(lib.sage_linear_act_backward(P(h1) if self.concat else None, h1p, None, P(agg2), agg2.stride(0), h1p, P(w2p),
-                                                  w2p.stride(0), e.h2, e.act2, P(out), out.stride(0), P(g_out), g_out.stride(0), b, None,
-                                                  P(g_w2p), g_w2p.stride(0), P(g_x2), g_x2.stride(0), st), "linear_act_backward (layer 2)")
-        # ---- d h1: the means scatter back to the frontier rows, the concat encoder's own rows are the first B
-        self._grad_h1.zero_()
-        g_agg2 = g_x2[:, (mult - 1) * h1p:]
-        native.check(lib.sage_gather_mean_backward(P(g_agg2), g_x2.stride(0), h1p, P(row2), P(cnt2), k2, b, None, None, P(self_row2),
-                                                   P(self._grad_h1), L.max_s1, h1p, st), "gather_mean_backward (layer 2)")
-        if self.concat:
-            self._grad_h1[:b] += g_x2[:, :h1p]
-        # ---- layer 1 backward: only dW1 (the table is frozen); agg1 from the workspace (split layer) or recomputed on the live rows
-        self_row1 = s1_nodes if e.agg_self_loop else None
-        if L.layer1_split:
-            # the split layer (sliced gather + contraction) left the means of this very forward in the workspace: no second gather
-            agg1 = e._view(L.agg1, L.max_s1 * d0p, torch.float32).view(L.max_s1, d0p)
-        else:
-            ops.gather_mean(e.table, nbr1, cnt1, self_row=self_row1, any_nonempty=self._any, n_dev=self._nlive, out=self._agg1)
-            agg1 = self._agg1
-        g_w1p = torch.zeros_like(w1p)
-        native.check(lib.sage_linear_act_backward(P(e.table) if self.concat else None, e.table_ld, P(s1_nodes) if self.concat else None,
-                                                  P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, e.act1, P(h1), h1p,
-                                                  P(self._grad_h1), h1p, L.max_s1, P(self._nlive), P(g_w1p), g_w1p.stride(0), None, 0, st),
-                     "linear_act_backward (layer 1)")
-        # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
-        if e._padded:
-            g_w1 = torch.cat([g_w1p[:e.h1, c * d0p: c * d0p + e.d0] for c in range(mult)], 1)
-            g_w2 = torch.cat([g_w2p[:, c * h1p: c * h1p + e.h1] for c in range(mult)], 1)
-        else:
-            g_w1, g_w2 = g_w1p, g_w2p
+        # both layers' weight gradients from the intermediates this forward left in the engine's workspace
+        g_w1, g_w2 = e.backward_weights(out, g_out)
         return loss.detach(), (g_w1, g_w2, g_cls)
 
     def step(self, seeds, labels, key, global_batch=None):
@@ -308,6 +257,9 @@ class EngineTrainer:
 
     def replay_step(self):
         self._step_graph.replay()
+        # the replay updated the weights without moving their version counters: an eager forward after it (validation, a
+        # plain step) must not find its cached planes / padded copies of W_{t-1} "up to date" 
+        self.engine.invalidate_weights()
         return self._loss_static
 
 

@@ -109,8 +109,8 @@ def test_engine_step_at_config3_size_gradients_and_step_time():
     assert all(torch.isfinite(w).all() for w in tr.parameters())
 
 
-@pytest.mark.parametrize("gcn,relabel", [(True, None), (False, "degree")])
-def test_captured_step_trains_like_the_eager_step(gcn, relabel):
+@pytest.mark.parametrize("gcn,relabel,hidden1", [(True, None, 64), (False, "degree", 64), (True, None, 30)])
+def test_captured_step_trains_like_the_eager_step(gcn, relabel, hidden1):
     """EngineTrainer.capture_step: forward + loss + backward + SGD of the batch at the queue cursor as ONE hipGraph.  Replaying it
     over a ring of mini-batches must leave the weights an eager loop over the same batches and keys leaves (fp32 atomics in the
     weight gradient: equal up to summation order), wrap around the ring, and report the same losses."""
@@ -125,7 +125,7 @@ def test_captured_step_trains_like_the_eager_step(gcn, relabel):
 
     def make():
         torch.manual_seed(5)
-        return EngineTrainer(rowptr, col, table, 5, hidden1=64, hidden2=32, num_sample1=7, num_sample2=9, gcn=gcn, lr=0.3, max_batch=256,
+        return EngineTrainer(rowptr, col, table, 5, hidden1=hidden1, hidden2=32, num_sample1=7, num_sample2=9, gcn=gcn, lr=0.3, max_batch=256,
                              relabel=relabel)
 
     eager = make()
@@ -148,6 +148,14 @@ def test_captured_step_trains_like_the_eager_step(gcn, relabel):
     for name, a, b in zip(("w1", "w2", "w_cls"), cap.parameters(), eager.parameters()):
         err = (a - b).abs().max().item() / b.abs().max().item()
         assert err <= 1e-4, f"{name}: captured vs eager {err:.2e}"
+    # a replay moves the weights but not their version counters; an EAGER forward after it (validation) must run on
+    # W_t, not on padded copies / bf16 planes of W_{t-1}: bit-identical to a fresh engine built from the trainer's weights
+    from sage355.engine import TwoHopEngine
+    val = torch.from_numpy(np.random.default_rng(77).choice(cand, 200, replace=False).astype(np.int32)).to(DEV)
+    fresh = TwoHopEngine(rowptr, col, table, cap.w1.clone(), cap.w2.clone(), 7, 9, concat=not gcn, max_batch=256, relabel=relabel)
+    assert torch.equal(cap.embed(val, key=5), fresh.forward(val, seed=5)), "eager forward after replays ran on stale weight caches"
+    sc, se = cap.scores(val, key=5), eager.scores(val, key=5)
+    assert (sc - se).abs().max().item() <= 2e-3 * se.abs().max().item()
 
 
 def test_engine_training_reaches_reference_f1_on_standin_cora_in_under_a_millisecond_per_step():
@@ -202,16 +210,16 @@ def test_engine_training_reaches_reference_f1_on_standin_pubmed():
     assert abs(mine - ref["f1_micro_mean"]) <= tol, (mine, ref["f1_micro_mean"], tol)
 
 
-def _dp_rank(rank, world, port, tmp):
+def _dp_rank(rank, world, port, tmp, d0=64, h1=32):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from sage355 import dist
     dist.init_from_env(backend="gloo")          # both ranks share cuda:0 here; on a node it is nccl (RCCL), one GPU per rank
     graph = rmat_graph(13, 150_000, seed=4, accel=None)
     gen = torch.Generator().manual_seed(1)
-    table = torch.randn(graph.num_nodes, 64, generator=gen).to(DEV)
+    table = torch.randn(graph.num_nodes, d0, generator=gen).to(DEV)
     rowptr, col = graph.to(DEV)
     torch.manual_seed(10 + rank)                # different initial weights per rank: the broadcast must make them equal
-    tr = EngineTrainer(rowptr, col, table, 4, hidden1=32, hidden2=16, num_sample1=5, num_sample2=5, gcn=True, max_batch=128)
+    tr = EngineTrainer(rowptr, col, table, 4, hidden1=h1, hidden2=16, num_sample1=5, num_sample2=5, gcn=True, max_batch=128)
     rs = np.random.default_rng(0)
     cand = np.nonzero(graph.degrees() > 0)[0]
     labels_all = torch.from_numpy(rs.integers(0, 4, graph.num_nodes)).to(DEV)
@@ -221,13 +229,16 @@ def _dp_rank(rank, world, port, tmp):
         mine = dist.shard_batch(list(batch), rank, world)
         ids = torch.as_tensor(np.asarray(mine, dtype=np.int32)).to(DEV)
         losses.append(float(tr.step(ids, labels_all[ids.long()], key=1000 * rank + step, global_batch=len(batch))))
+        if step == 0:
+            w_after_first = torch.cat([p.reshape(-1).cpu() for p in tr.parameters()])
     w = torch.cat([p.reshape(-1).cpu() for p in tr.parameters()])
-    torch.save({"w": w, "losses": losses}, os.path.join(tmp, f"r{rank}.pt"))
+    torch.save({"w": w, "losses": losses, "w_after_first": w_after_first}, os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_engine_trainer_data_parallel_one_flat_all_reduce_keeps_replicas_identical(tmp_path):
+@pytest.mark.parametrize("d0,h1", [(64, 32), (66, 30)])       # (66, 30): zero-padded widths -- cached copies of the weights inside the engine
+def test_engine_trainer_data_parallel_one_flat_all_reduce_keeps_replicas_identical(tmp_path, d0, h1):
     """seeds shard across ranks, graph / table / weights are replicated, ONE all-reduce of the weight gradients per
     step.  Two ranks (gloo, sharing this box's GPU; RCCL on a node): started from different weights, they must be bit-identical
     after the broadcast and stay so through six steps, each with its own sampler stream."""
@@ -237,7 +248,30 @@ def test_engine_trainer_data_parallel_one_flat_all_reduce_keeps_replicas_identic
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_dp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_rank, args=(2, port, str(tmp_path), d0, h1), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(a["w"], b["w"]), "replicas diverged"
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+    # identical replicas and finite losses are what the all-reduce guarantees even when a rank's FIRST step ran on caches
+    # of its own pre-broadcast weights.  The first step must be the single-process step from rank 0's weights: the sum over the
+    # two shards' gradients (each with its rank's sampler key), applied once.
+    from sage355 import dist
+    graph = rmat_graph(13, 150_000, seed=4, accel=None)
+    gen = torch.Generator().manual_seed(1)
+    table = torch.randn(graph.num_nodes, d0, generator=gen).to(DEV)
+    rowptr, col = graph.to(DEV)
+    torch.manual_seed(10)                       # rank 0's initial weights
+    tr = EngineTrainer(rowptr, col, table, 4, hidden1=h1, hidden2=16, num_sample1=5, num_sample2=5, gcn=True, max_batch=128)
+    rs = np.random.default_rng(0)
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    labels_all = torch.from_numpy(rs.integers(0, 4, graph.num_nodes)).to(DEV)
+    batch = rs.choice(cand, 256, replace=False)
+    total = [torch.zeros_like(p) for p in tr.parameters()]
+    for r in range(2):
+        ids = torch.as_tensor(np.asarray(dist.shard_batch(list(batch), r, 2), dtype=np.int32)).to(DEV)
+        _, g = tr.grads(ids, labels_all[ids.long()], key=1000 * r, global_batch=256)
+        for t, gi in zip(total, g):
+            t += gi
+    want = torch.cat([(p - tr.lr * t).reshape(-1).cpu() for p, t in zip(tr.parameters(), total)])
+    err = (a["w_after_first"] - want).abs().max().item() / want.abs().max().item()
+    assert err <= 1e-5, f"first data-parallel step differs from the single-process step from rank 0's weights: {err:.2e}"

@@ -156,6 +156,7 @@ def test_adjacency_cache_detects_in_place_mutation_and_is_bounded(monkeypatch):
         return FakeGraph(adj)
 
     monkeypatch.setattr(encoders, "csr_from_adj_lists", fake_csr)
+    monkeypatch.setattr(encoders, "_CSR_RECHECK_EVERY", 1)       # full fingerprint on every call for this part
     encoders.invalidate_adjacency()
     adj = defaultdict(set, {0: {1}, 1: {0, 2}, 2: {1}})
     encoders._device_csr(adj, 3, "cpu")
@@ -171,6 +172,24 @@ def test_adjacency_cache_detects_in_place_mutation_and_is_bounded(monkeypatch):
     encoders.invalidate_adjacency(adj)
     encoders._device_csr(adj, 3, "cpu")
     assert calls == [4, 6, 6]
+    # the O(N) fingerprint runs only every _CSR_RECHECK_EVERY-th call (a new key triggers it at once); an edit that
+    # keeps the key count is seen at the next periodic check at the latest, and a MOVED edge (same counts) is seen too
+    monkeypatch.setattr(encoders, "_CSR_RECHECK_EVERY", 8)
+    encoders.invalidate_adjacency()
+    del calls[:]
+    adj = defaultdict(set, {0: {1}, 1: {0, 2}, 2: {1}, 3: set()})
+    encoders._device_csr(adj, 4, "cpu")
+    adj[0].discard(1); adj[1].discard(0); adj[0].add(3); adj[3].add(0)      # moved: same non-empty count? no -- 3 becomes non-empty
+    adj[3].discard(0); adj[0].discard(3); adj[0].add(2); adj[2].add(0)      # now 0-2 instead of 0-1: same counts, same degree total
+    for _ in range(6):
+        encoders._device_csr(adj, 4, "cpu")
+    assert calls == [4]                          # not yet re-fingerprinted
+    for _ in range(3):
+        encoders._device_csr(adj, 4, "cpu")
+    assert calls == [4, 4]                       # the periodic check saw the moved edge
+    adj[9].add(0)                                # a new key: checked at once
+    encoders._device_csr(adj, 4, "cpu")
+    assert calls == [4, 4, 5]
     keep = [defaultdict(set, {0: {i + 1}}) for i in range(encoders._CSR_CACHE_MAX + 3)]
     for a in keep:
         encoders._device_csr(a, 0, "cpu")
