@@ -36,6 +36,7 @@ const sage_tunables_t& sage_tunables() {
         x.gather_variant = env_int("SAGE_G_VARIANT", 1, 0, 2);
         x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU, 32, 512);
         x.bwd_blocks = env_int("SAGE_BWD_BLOCKS", 512, 16, 4096);
+        x.bwd_direct_blocks = env_int("SAGE_BWD_DIRECT_BLOCKS", 256, 16, 1024);
         const int so = env_int("SAGE_SO_THREADS", 1024, 256, 1024);
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);

@@ -4,10 +4,14 @@
 // (model.py:249 loss.backward()).  Here:
 //   dZ      = grad_out * act'(out)                         (fused into the operand loads)
 //   grad_x  = dZ . W                      [n, ds+dim]      fp32 MFMA, reduction over out_dim
-//   grad_W += dZ^T . [self | agg]         [out_dim, ds+dim] fp32 MFMA, reduction over the n rows,
-//                                                          split across blockIdx.z, fp32 atomics
-//   grad_table[row(nbr[r,j])] += grad_agg[r] / c           fp32 atomics (mean backward = scatter)
-// One generic 64x128x32 MFMA tile kernel with functor operands serves both GEMMs; the training
+//   grad_W += dZ^T . [self | agg]         [out_dim, ds+dim] fp32 MFMA, reduction over the n rows split over blocks:
+//                                                          * _ws entry (round 3): every split writes its partial tile, one reduce kernel
+//                                                            adds them in split order -- bitwise reproducible, as model.py:249 is on a CPU;
+//                                                            operands straight from HBM in MFMA register order (bwd_dw_direct_kernel)
+//                                                          * legacy entry: fp32 atomics (order of arrival)
+//   grad_table[row(nbr[r,j])] += grad_agg[r] / c           legacy: fp32 atomics (mean backward = scatter); the reproducible form
+//                                                          (inverted index, sage_backward_det.hip) sums every row's list in (r, j) order
+// One generic 64x128x32 MFMA tile kernel with functor operands serves grad_x and the odd-shaped grad_W; the training
 // operand loads are guarded scalar loads along the index that is contiguous in memory, transposed into LDS.
 #include "sage_internal.h"
 
@@ -44,7 +48,9 @@ struct Xcat {  // X(m, j) = [self | agg](m, j), the forward's operand (encoders.
 template <int MODE>
 __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const float* __restrict__ W, int64_t ldw,
                                                        int M, int N, int K, float* __restrict__ C, int64_t ldc, int ksplit,
-                                                       const int32_t* __restrict__ rows_dev) {
+                                                       const int32_t* __restrict__ rows_dev, int64_t zstride) {
+    // zstride != 0 (MODE 1 only): split z STORES its tile into C + z * zstride (a partial sum for dw_reduce_kernel) instead of
+    // adding it to C with atomics; a split with no rows stores zeros.
     __shared__ float smem[(BM + BN) * LDP];
     if (rows_dev) {                                   // the number of layer rows lives on the device (frontier size): it bounds the
         if (MODE == 0) M = min(*rows_dev, M);         // output rows of grad_x and the reduction length of grad_W
@@ -56,7 +62,8 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kper = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend && zstride == 0) return;
+    if (zstride != 0) C += (int64_t)blockIdx.z * zstride;
     const int wave_n0 = nb0 + wave * 32;
     const bool wave_active = wave_n0 < N;
     f32x16 acc0, acc1;
@@ -124,6 +131,9 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const floa
                 if (MODE == 0) {
                     if (g0 < M) C[(int64_t)g0 * ldc + col] = acc0[reg];
                     if (g1 < M) C[(int64_t)g1 * ldc + col] = acc1[reg];
+                } else if (zstride != 0) {
+                    if (g0 < M) C[(int64_t)g0 * ldc + col] = acc0[reg];
+                    if (g1 < M) C[(int64_t)g1 * ldc + col] = acc1[reg];
                 } else {
                     if (g0 < M) atomicAdd(&C[(int64_t)g0 * ldc + col], acc0[reg]);
                     if (g1 < M) atomicAdd(&C[(int64_t)g1 * ldc + col], acc1[reg]);
@@ -131,6 +141,110 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const floa
             }
         }
     }
+}
+
+// ---- weight gradient, operands straight from HBM in MFMA register order (round 3) -------------------------------------------------
+// grad_W[m][n] = sum_k dZ(k, m) X(k, n): the reduction index k is the ROW index of both operands, so lane (i = l & 31, h = l >> 5)
+// of v_mfma_f32_32x32x2_f32 wants A = dZ[k0 + h][m], B = X[k0 + h][n] -- row-major operands need no transpose at all.  With 8-byte
+// loads a lane holds two consecutive m (two consecutive n): two A and two B fragments, i.e. a 64 x 64 output tile per wave whose rows
+// are simply permuted (fragment e owns rows m0 + 2 i + e), undone when the tile is stored.  512-thread blocks: 2 (M halves) x 4
+// (64-column groups) = a 128 x 256 tile per block; a block owns a contiguous range of k and STORES its partial tile; dw_reduce_kernel
+// adds the partials in block order, so the result does not depend on which block finished first (the generic kernel's atomics did:
+// captured and eager steps agreed to 1e-4 only).  PF k-pairs (3 x PF loads per lane) are in flight per trip, two waves per SIMD
+// take turns on the matrix pipe.  Measured at config 3 (23.6 k x 128 x 256): see DESIGN.md.
+struct DwArgs {
+    const float* gout; int64_t ldg; const float* out; int64_t ldo; int act;     // dZ(k, m) = gout[k][m] * act'(out[k][m])
+    const float* x; int64_t ldx; const int32_t* index; int x_rows;              // X(k, n) = x[index ? index[k] : k][n]
+    int M, Nx, n_rows; const int32_t* rows_dev;
+    float* partial; int64_t ldp; int col_off; int nsplit;                       // partial[split][m][col_off + n]
+};
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+template <bool INDEXED>
+__global__ __launch_bounds__(512) void bwd_dw_direct_kernel(const DwArgs a) {
+    constexpr int PF = 4;
+    int nrows = a.n_rows;
+    if (a.rows_dev) nrows = min(*a.rows_dev, nrows);
+    nrows = max(nrows, 0);
+    const int per = (((nrows + a.nsplit - 1) / a.nsplit) + 1) & ~1;       // rows per split, even (whole k-pairs)
+    const int kbeg = min((int)blockIdx.x * per, nrows), kend = min(nrows, kbeg + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.z * 128 + (wave >> 2) * 64, n0 = blockIdx.y * 256 + (wave & 3) * 64;
+    if (m0 >= a.M || n0 >= a.Nx) return;                                  // no barrier in this kernel
+    const int i = lane & 31, h = lane >> 5;
+    const int mc = m0 + 2 * i, nc = n0 + 2 * i;
+    const bool mok = mc < a.M, nok = nc < a.Nx;                           // M, Nx even (host-checked)
+    const float* gp = a.gout + min(mc, a.M - 2);
+    const float* yp = a.out + min(mc, a.M - 2);
+    const float* xp = a.x + min(nc, a.Nx - 2);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * PF) {
+        f32x2 g[PF], y[PF], xv[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {                                    // rows past the range: clamped address, zeroed below
+            const int rc = min(k0 + 2 * p + h, kend - 1);
+            int64_t xr = rc;
+            if (INDEXED) xr = min(max(a.index[rc], 0), a.x_rows - 1);
+            g[p] = *reinterpret_cast<const f32x2*>(gp + (int64_t)rc * a.ldg);
+            y[p] = *reinterpret_cast<const f32x2*>(yp + (int64_t)rc * a.ldo);
+            xv[p] = *reinterpret_cast<const f32x2*>(xp + xr * a.ldx);
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const bool live = mok && (k0 + 2 * p + h) < kend;
+            float dz[2], xx[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v = g[p][e];
+                if (a.act == SAGE_ACT_RELU) v = y[p][e] > 0.f ? v : 0.f;
+                else if (a.act == SAGE_ACT_SIGMOID) v = v * y[p][e] * (1.f - y[p][e]);
+                dz[e] = live ? v : 0.f;
+                xx[e] = nok ? xv[p][e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[e], xx[f], acc[e][f], 0, 0, 0);
+        }
+    }
+    float* P = a.partial + (int64_t)blockIdx.x * a.M * a.ldp + a.col_off;
+    if (nok) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * h) + e;
+                if (m < a.M) *reinterpret_cast<f32x2*>(P + (int64_t)m * a.ldp + nc) = f32x2{acc[e][0][reg], acc[e][1][reg]};
+            }
+    }
+}
+
+// grad_W[m][n] += partial[0][m][n] + partial[1][m][n] + ... in split order (one thread per element: coalesced along n)
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, int nsplit, int M, int K, int64_t ldp,
+                                                       float* __restrict__ gw, int64_t ldgw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * K) return;
+    const int m = idx / K, n = idx % K;
+    const float* p = partial + (int64_t)m * ldp + n;
+    const int64_t stride = (int64_t)M * ldp;
+    float s = 0.f;
+    int z = 0;
+    for (; z + 8 <= nsplit; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)(z + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < nsplit; ++z) s += __builtin_nontemporal_load(p + (int64_t)z * stride);
+    gw[(int64_t)m * ldgw + n] += s;
 }
 
 // mean backward: one wave per destination row, lanes over columns
@@ -180,11 +294,19 @@ __global__ __launch_bounds__(256) void gather_mean_bwd_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg,
-                                        int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
-                                        int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
-                                        const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
-                                        sage_stream_t stream) {
+namespace {
+// splits of the reduction over the rows: the direct kernel's row ranges / the generic kernel's K splits
+int dw_direct_splits(int n) { return max(1, min(sage_tunables().bwd_direct_blocks, sage_cdiv(n, 64))); }
+int dw_generic_splits(int n, int out_dim, int K) {
+    const int tiles = sage_cdiv(out_dim, BM) * sage_cdiv(K, BN);
+    return max(1, min(sage_cdiv(n, 4 * BK), sage_tunables().bwd_blocks / tiles));
+}
+
+int linear_act_backward_impl(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg,
+                             int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
+                             int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
+                             const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                             void* workspace, size_t workspace_bytes, bool reproducible, sage_stream_t stream) {
     SAGE_REQUIRE(agg && weight && out && grad_out, "linear_act_backward: NULL array");
     SAGE_REQUIRE(n >= 0 && dim >= 1 && out_dim >= 1, "linear_act_backward: n = %d, dim = %d, out_dim = %d", n, dim, out_dim);
     SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "linear_act_backward: act = %d", act);
@@ -193,23 +315,86 @@ extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, 
     SAGE_REQUIRE(!self_tab || ld_self >= dim, "linear_act_backward: ld_self");
     SAGE_REQUIRE(!grad_weight || ldgw >= K, "linear_act_backward: ldgw = %lld < %d", (long long)ldgw, K);
     SAGE_REQUIRE(!grad_x || ldgx >= K, "linear_act_backward: ldgx = %lld < %d", (long long)ldgx, K);
+    if (reproducible && grad_weight) {
+        const size_t need = sage_linear_act_backward_workspace_bytes(n, dim, self_tab ? 1 : 0, out_dim);
+        SAGE_REQUIRE(workspace && sage_aligned(workspace, 16) && workspace_bytes >= need,
+                     "linear_act_backward_ws: workspace %zu bytes (need %zu, 16-byte aligned)", workspace_bytes, need);
+    }
     if (n == 0) return SAGE_OK;
     hipStream_t st = (hipStream_t)stream;
     const Dz dz{out, ldo, grad_out, ldg, act};
     const Xcat x{self_tab, ld_self, self_index, agg, ld_agg, ds};
     if (grad_x) {
         dim3 grid(sage_cdiv(n, BM), sage_cdiv(K, BN), 1);
-        hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1, n_dev);
+        hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1, n_dev, (int64_t)0);
         SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_x>");
     }
-    if (grad_weight) {
-        const int tiles = sage_cdiv(out_dim, BM) * sage_cdiv(K, BN);
-        const int ksplit = max(1, min(sage_cdiv(n, 4 * BK), sage_tunables().bwd_blocks / tiles));
+    if (!grad_weight) return SAGE_OK;
+    if (!reproducible) {
+        const int ksplit = dw_generic_splits(n, out_dim, K);
         dim3 grid(sage_cdiv(out_dim, BM), sage_cdiv(K, BN), ksplit);
-        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, grad_weight, ldgw, ksplit, n_dev);
+        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, grad_weight, ldgw, ksplit, n_dev, (int64_t)0);
         SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_w>");
+        return SAGE_OK;
     }
+    float* partial = (float*)workspace;
+    const int64_t ldp = K;
+    int nsplit;
+    // 8-byte operand loads: even widths and leading dimensions, 8-byte aligned bases (the engine's padded widths always are)
+    const bool direct = out_dim % 2 == 0 && dim % 2 == 0 && ldg % 2 == 0 && ldo % 2 == 0 && ld_agg % 2 == 0 && (!self_tab || ld_self % 2 == 0) &&
+                        sage_aligned(grad_out, 8) && sage_aligned(out, 8) && sage_aligned(agg, 8) && (!self_tab || sage_aligned(self_tab, 8));
+    if (direct) {
+        nsplit = dw_direct_splits(n);
+        DwArgs a{grad_out, ldg, out, ldo, act, agg, ld_agg, nullptr, n, out_dim, dim, n, n_dev, partial, ldp, ds, nsplit};
+        dim3 grid(nsplit, sage_cdiv(dim, 256), sage_cdiv(out_dim, 128));
+        hipLaunchKernelGGL(bwd_dw_direct_kernel<false>, grid, dim3(512), 0, st, a);       // the neighbour means: columns [ds, ds + dim)
+        SAGE_CHECK_LAUNCH("bwd_dw_direct_kernel<agg>");
+        if (self_tab) {                                                                    // the nodes' own rows: columns [0, dim)
+            a.x = self_tab; a.ldx = ld_self; a.col_off = 0;
+            if (self_index) {
+                a.index = self_index; a.x_rows = 1 << 30;       // the caller vouches for the index range, as in the forward
+                hipLaunchKernelGGL(bwd_dw_direct_kernel<true>, grid, dim3(512), 0, st, a);
+            } else {
+                hipLaunchKernelGGL(bwd_dw_direct_kernel<false>, grid, dim3(512), 0, st, a);
+            }
+            SAGE_CHECK_LAUNCH("bwd_dw_direct_kernel<self>");
+        }
+    } else {
+        nsplit = dw_generic_splits(n, out_dim, K);
+        dim3 grid(sage_cdiv(out_dim, BM), sage_cdiv(K, BN), nsplit);
+        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, partial, ldp, nsplit, n_dev,
+                           (int64_t)out_dim * ldp);
+        SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_w partials>");
+    }
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(sage_cdiv((int64_t)out_dim * K, 256)), dim3(256), 0, st, partial, nsplit, out_dim, K, ldp, grad_weight, ldgw);
+    SAGE_CHECK_LAUNCH("dw_reduce_kernel");
     return SAGE_OK;
+}
+}  // namespace
+
+extern "C" size_t sage_linear_act_backward_workspace_bytes(int32_t n, int32_t dim, int32_t has_self, int32_t out_dim) {
+    if (n <= 0 || dim <= 0 || out_dim <= 0) return 16;
+    const int K = (has_self ? 2 : 1) * dim;
+    const int splits = max(dw_direct_splits(n), dw_generic_splits(n, out_dim, K));
+    return (size_t)splits * out_dim * K * sizeof(float) + 16;
+}
+
+extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg,
+                                        int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
+                                        int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
+                                        const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                                        sage_stream_t stream) {
+    return linear_act_backward_impl(self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw, out_dim, act, out, ldo, grad_out, ldg, n,
+                                    n_dev, grad_weight, ldgw, grad_x, ldgx, nullptr, 0, false, stream);
+}
+
+extern "C" int sage_linear_act_backward_ws(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg,
+                                           int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
+                                           int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
+                                           const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                                           void* workspace, size_t workspace_bytes, sage_stream_t stream) {
+    return linear_act_backward_impl(self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw, out_dim, act, out, ldo, grad_out, ldg, n,
+                                    n_dev, grad_weight, ldgw, grad_x, ldgx, workspace, workspace_bytes, true, stream);
 }
 
 extern "C" int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int32_t dim, const int32_t* nbr, const int32_t* cnt,

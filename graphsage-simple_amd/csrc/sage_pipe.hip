@@ -16,6 +16,17 @@
 // roles on the same stream is skipped), so {S,G,D,L} = one stream degenerates to sage_forward2.
 // Results are bit-identical to sage_forward2 on the same (seeds, key): same kernels, same workspaces' layout.
 // The reference has no counterpart: model.py:240-252 runs one batch at a time on the host.
+//
+// Stream capture (round 3).  fork -> submits -> join can be captured into ONE hipGraph (hipStreamBeginCapture on the caller's
+// stream; the role streams join the capture through the fork event) with ONE exception, found with a stand-alone program of
+// trivial kernels (experiments/r03/capture_repro.cpp, patterns 0-17 on ROCm 7.2): hipStreamEndCapture segfaults when stream S
+// waits, by hipStreamWaitEvent, for the event L recorded for an EARLIER batch -- the workspace-release edge L(b) -> S(b + depth);
+// fresh events per record, relaxed capture mode, system-fence flags and a relay through a helper stream change nothing, the same
+// pattern without that wait (or with at most `depth` batches, which never need it) captures and replays correctly, and so do
+// two-stream patterns with a wait on an event that is no longer its stream's tail.  Expressed WITHOUT an event -- the node L(b)
+// left as the tail of stream L is read back with hipStreamGetCaptureInfo_v2 right after it is enqueued, and added to S's next node
+// with hipStreamUpdateCaptureDependencies -- the very same graph captures, instantiates and replays correctly (patterns 15, 17).
+// submit_one does exactly that while the role streams are capturing; eager submission keeps the event.
 #include <stdlib.h>
 
 #include <new>
@@ -32,6 +43,10 @@ struct sage_pipe {
     hipEvent_t ev[4][SAGE_PIPE_MAX_DEPTH];              // [role][slot]: role's work on the slot's batch is enqueued
     hipEvent_t ev_fork;
     uint64_t submitted;
+    // while capturing: the graph node(s) layer 2 of the slot's last batch left as the tail of stream L, and the capture they belong to
+    hipGraphNode_t cap_nodes[SAGE_PIPE_MAX_DEPTH][4];
+    int cap_count[SAGE_PIPE_MAX_DEPTH];
+    unsigned long long cap_id[SAGE_PIPE_MAX_DEPTH];
 };
 
 namespace {
@@ -50,6 +65,17 @@ int wait_on(sage_pipe* p, int consumer, int producer, int slot) {
         sage_set_error("pipe: hipStreamWaitEvent failed");
         return SAGE_ELAUNCH;
     }
+    return SAGE_OK;
+}
+// 0 = not capturing; otherwise the id of the capture the stream belongs to
+int capture_id(hipStream_t st, unsigned long long* id) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    *id = 0;
+    if (hipStreamGetCaptureInfo_v2(st, &status, id, nullptr, nullptr, nullptr) != hipSuccess) {
+        sage_set_error("pipe: hipStreamGetCaptureInfo_v2 failed");
+        return SAGE_ELAUNCH;
+    }
+    if (status != hipStreamCaptureStatusActive) *id = 0;
     return SAGE_OK;
 }
 int record(sage_pipe* p, int role, int slot, bool needed) {
@@ -85,6 +111,7 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     p->depth = depth;
     p->ws_bytes = workspace_bytes;
     p->submitted = 0;
+    for (int i = 0; i < SAGE_PIPE_MAX_DEPTH; ++i) { p->cap_count[i] = 0; p->cap_id[i] = 0; }
     for (int i = 0; i < depth; ++i) p->ws[i] = workspaces[i];
     for (int r = 0; r < 4; ++r) p->st[r] = (hipStream_t)streams[r];
     for (int r = 0; r < 4; ++r)
@@ -133,8 +160,24 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     const sage_model_t* m = &p->model;
     void* ws = p->ws[slot];
     // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
-    if (!fresh_slot)
-        if (int rc = wait_on(p, RS, RL, slot)) return rc;
+    unsigned long long cap = 0;
+    if (int rc = capture_id(p->st[RS], &cap)) return rc;
+    if (!fresh_slot && p->st[RS] != p->st[RL]) {
+        if (cap != 0) {
+            // captured: the release edge as an explicit node dependency (an event wait here crashes hipStreamEndCapture, see above)
+            SAGE_REQUIRE(p->cap_id[slot] == cap && p->cap_count[slot] > 0,
+                         "pipe: inside a stream capture the first `depth` submits must find their workspaces free: join everything "
+                         "submitted before, begin the capture, and pass segment_start (sage_pipe_submit_many) / call sage_pipe_reset");
+            if (hipStreamUpdateCaptureDependencies(p->st[RS], p->cap_nodes[slot], (size_t)p->cap_count[slot], hipStreamAddCaptureDependencies) != hipSuccess) {
+                sage_set_error("pipe: hipStreamUpdateCaptureDependencies failed");
+                return SAGE_ELAUNCH;
+            }
+        } else {
+            SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset "
+                                               "(after synchronising) before submitting eagerly again");
+            if (int rc = wait_on(p, RS, RL, slot)) return rc;
+        }
+    }
 #ifndef SAGE_PIPE_SKIP_S   // diagnostic builds only (experiments/ab_build.sh).  _G and _D may be skipped alone (stale data downstream); _S and _L
                            // only together with everything else ("events only"): the samplers fill and layer 2 wipes the frontier hash, and
                            // one without the other leaves a full table behind (an outer sampler probing it took 67 ms per batch)
@@ -163,7 +206,32 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, out, ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
 #endif
     if (int rc = record(p, RL, slot, p->st[RS] != p->st[RL])) return rc;
+    p->cap_id[slot] = 0;
+    p->cap_count[slot] = 0;
+    if (cap != 0 && p->st[RS] != p->st[RL]) {               // remember the node layer 2 left as the tail of stream L
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        unsigned long long id = 0;
+        const hipGraphNode_t* deps = nullptr;
+        size_t ndeps = 0;
+        if (hipStreamGetCaptureInfo_v2(p->st[RL], &status, &id, nullptr, &deps, &ndeps) != hipSuccess || status != hipStreamCaptureStatusActive ||
+            ndeps < 1 || ndeps > 4) {
+            sage_set_error("pipe: cannot read the tail of stream L during capture (%zu nodes)", ndeps);
+            return SAGE_ELAUNCH;
+        }
+        for (size_t i = 0; i < ndeps; ++i) p->cap_nodes[slot][i] = deps[i];
+        p->cap_count[slot] = (int)ndeps;
+        p->cap_id[slot] = id;
+    }
     ++p->submitted;
+    return SAGE_OK;
+}
+
+// Forget every submit: the next `depth` submits find their workspaces free.  The caller has synchronised (or joined) everything
+// submitted before -- e.g. after a stream capture ended, before eager submission resumes on the same pipe.
+extern "C" int sage_pipe_reset(sage_pipe_t* p) {
+    SAGE_REQUIRE(p, "pipe_reset: NULL pipe");
+    p->submitted = 0;
+    for (int i = 0; i < SAGE_PIPE_MAX_DEPTH; ++i) { p->cap_count[i] = 0; p->cap_id[i] = 0; }
     return SAGE_OK;
 }
 

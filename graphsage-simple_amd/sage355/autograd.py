@@ -49,12 +49,17 @@ class _LinearAct(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0] or (self_tab is not None and ctx.needs_input_grad[2])
         grad_w = torch.zeros_like(weight) if ctx.needs_input_grad[1] else None
         grad_x = torch.empty((n, kw), dtype=torch.float32, device=agg.device) if need_x else None
-        rc = native.lib().sage_linear_act_backward(
+        # the reproducible form: partial tiles in a workspace, added in a fixed order (no fp32 atomics)
+        lib = native.lib()
+        ws = torch.empty(max(256, lib.sage_linear_act_backward_workspace_bytes(n, dim, int(self_tab is not None), out_dim)),
+                         dtype=torch.uint8, device=agg.device) if grad_w is not None else None
+        rc = lib.sage_linear_act_backward_ws(
             native.ptr(self_tab), self_tab.stride(0) if self_tab is not None else 0, native.ptr(self_index),
             native.ptr(agg), agg.stride(0), dim, native.ptr(weight), weight.stride(0), out_dim, int(ctx.act),
             native.ptr(out), out.stride(0), native.ptr(grad_out), grad_out.stride(0), n, None,
             native.ptr(grad_w), grad_w.stride(0) if grad_w is not None else 0,
-            native.ptr(grad_x), grad_x.stride(0) if grad_x is not None else 0, native.stream_handle())
+            native.ptr(grad_x), grad_x.stride(0) if grad_x is not None else 0,
+            native.ptr(ws), ws.numel() if ws is not None else 0, native.stream_handle())
         native.check(rc, "linear_act_backward")
         grad_agg = grad_self = None
         if grad_x is not None:

@@ -343,22 +343,36 @@ class TwoHopEngine:
         nbr1 = self._view(L.nbr1, L.max_s1 * k1, torch.int32).view(L.max_s1, k1)
         cnt1 = self._view(L.cnt1, L.max_s1, torch.int32)
         s1_nodes = self._view(L.s1_nodes, L.max_s1, torch.int32)
-        # ---- layer 2 backward: agg2 is recomputed (one small gather), then dW2 and d[h1_self | agg2]
+        def scratch(name, nbytes):
+            t = sc.get(name)
+            if t is None or t.numel() < nbytes:
+                t = sc[name] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+            return t
+
+        # ---- layer 2 backward: agg2 is recomputed (one small gather), then dW2 and d[h1_self | agg2].  The *_ws entry points are
+        #      the reproducible forms (partial tiles added in a fixed order; inverted index instead of atomics): two runs of one
+        #      schedule give the same bits, and a captured step equals the eager one bit for bit
         agg2 = ops.gather_mean(h1, row2, cnt2, self_row=self_row2, any_nonempty=sc["any"])
         mult = 2 if self.concat else 1
         g_w2p = torch.zeros_like(w2p)
         g_x2 = torch.empty(b, mult * h1p, device=dev)
-        native.check(lib.sage_linear_act_backward(P(h1) if self.concat else None, h1p, None, P(agg2), agg2.stride(0), h1p, P(w2p),
-                                                  w2p.stride(0), self.h2, self.act2, P(out), out.stride(0), P(grad_out), grad_out.stride(0), b, None,
-                                                  P(g_w2p), g_w2p.stride(0), P(g_x2) if need_w1 else None, g_x2.stride(0), st),
-                     "linear_act_backward (layer 2)")
+        ws2 = scratch("ws_dw2", lib.sage_linear_act_backward_workspace_bytes(b, h1p, int(self.concat), self.h2))
+        native.check(lib.sage_linear_act_backward_ws(P(h1) if self.concat else None, h1p, None, P(agg2), agg2.stride(0), h1p, P(w2p),
+                                                     w2p.stride(0), self.h2, self.act2, P(out), out.stride(0), P(grad_out), grad_out.stride(0), b, None,
+                                                     P(g_w2p), g_w2p.stride(0), P(g_x2) if need_w1 else None, g_x2.stride(0),
+                                                     P(ws2), ws2.numel(), st), "linear_act_backward (layer 2)")
         g_w1p = None
         if need_w1:
-            # ---- d h1: the means scatter back to the frontier rows, the concat encoder's own rows are the first B
-            sc["grad_h1"].zero_()
+            # ---- d h1: every frontier row sums the means it is a member of (rows [0, nlive) are written, nothing is zeroed);
+            #      the concat encoder's own rows are the first B
             g_agg2 = g_x2[:, (mult - 1) * h1p:]
-            native.check(lib.sage_gather_mean_backward(P(g_agg2), g_x2.stride(0), h1p, P(row2), P(cnt2), k2, b, None, None, P(self_row2),
-                                                       P(sc["grad_h1"]), L.max_s1, h1p, st), "gather_mean_backward (layer 2)")
+            need = lib.sage_gather_mean_backward_workspace_bytes(b, k2, L.max_s1)
+            if need == 0:
+                raise native.SageError("gather_mean_backward_ws: workspace size query failed")
+            wsg = scratch("ws_gm", need)
+            native.check(lib.sage_gather_mean_backward_ws(P(g_agg2), g_x2.stride(0), h1p, P(row2), P(cnt2), k2, b, None, None, P(self_row2),
+                                                          P(sc["grad_h1"]), L.max_s1, P(sc["nlive"]), h1p, P(wsg), wsg.numel(), st),
+                         "gather_mean_backward (layer 2)")
             if self.concat:
                 sc["grad_h1"][:b] += g_x2[:, :h1p]
             # ---- layer 1 backward: only dW1 (the table is frozen); agg1 from the workspace (split layer) or recomputed on the live rows
@@ -372,9 +386,11 @@ class TwoHopEngine:
                 ops.gather_mean(self.table, nbr1, cnt1, self_row=self_row1, any_nonempty=sc["any"], n_dev=sc["nlive"], out=sc["agg1"])
                 agg1 = sc["agg1"]
             g_w1p = torch.zeros_like(w1p)
-            native.check(lib.sage_linear_act_backward(P(self.table) if self.concat else None, self.table_ld, P(s1_nodes) if self.concat else None,
-                                                      P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, self.act1, P(h1), h1p,
-                                                      P(sc["grad_h1"]), h1p, L.max_s1, P(sc["nlive"]), P(g_w1p), g_w1p.stride(0), None, 0, st),
+            ws1 = scratch("ws_dw1", lib.sage_linear_act_backward_workspace_bytes(L.max_s1, d0p, int(self.concat), h1p))
+            native.check(lib.sage_linear_act_backward_ws(P(self.table) if self.concat else None, self.table_ld, P(s1_nodes) if self.concat else None,
+                                                         P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, self.act1, P(h1), h1p,
+                                                         P(sc["grad_h1"]), h1p, L.max_s1, P(sc["nlive"]), P(g_w1p), g_w1p.stride(0), None, 0,
+                                                         P(ws1), ws1.numel(), st),
                          "linear_act_backward (layer 1)")
         # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
         if self._padded:
@@ -540,7 +556,34 @@ class RolePipeline:
             self._broken = rc == native.ELAUNCH
             native.check(rc, "pipe_submit_many")
 
+    def reset(self):
+        """Forget every submit (after synchronising): the next `depth` submits find their workspaces free."""
+        native.check(native.lib().sage_pipe_reset(self._h), "pipe_reset")
+
+    def capture(self, seeds, keys, out, stream=None):
+        """The n batches seeds[i] / keys[i] -> out[i % slots] through the role streams, captured as ONE hipGraph:
+        fork -> submit_many -> join on `stream` (default: a stream of the pipe's own).  -> (torch.cuda.CUDAGraph, stream);
+        `graph.replay()` under `torch.cuda.stream(stream)` then runs all n batches with a single host call.  The graph embeds
+        these seeds / keys / out tensors (keep them alive and unmodified in place of new data: write new seeds INTO `seeds`).
+        Bit-identical to submit() on the same batches.  The pipe must be idle (synchronise first); eager submission afterwards
+        needs reset()."""
+        self._sync_weights()
+        self._check_usable()
+        if stream is None:
+            stream = getattr(self, "_cap_stream", None) or torch.cuda.Stream(device=self.device)
+            self._cap_stream = stream
+        torch.cuda.synchronize()
+        self.reset()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(g, stream=stream):
+                self.fork(stream)
+                self.submit_many(seeds, keys, out, segment_start=True)
+                self.join(stream)
+        self.reset()
+        self._keep.append((seeds, out))
+        return g, stream
+
     def synchronize(self):
         for s in self._streams.values():
             s.synchronize()
-        self._keep.clear()

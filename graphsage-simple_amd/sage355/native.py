@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
 TAG_INNER, TAG_OUTER, TAG_INNER_SELF = 1, 2, 3
 MAX_FANOUT = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 EINVAL, EUNSUPPORTED, ELAUNCH, ENOSPACE = -1, -2, -3, -4      # include/sage355.h
 
 # every symbol include/sage355.h declares (tests check the library exports each one)
@@ -24,9 +24,11 @@ SYMBOLS = [
     "sage_frontier_insert", "sage_gather_mean", "sage_linear_act", "sage_layer_forward", "sage_layer_forward_supported",
     "sage_forward2_layout", "sage_forward2_init", "sage_forward2", "sage_forward2_profiled",
     "sage_linear_act_backward", "sage_gather_mean_backward",
+    "sage_linear_act_backward_workspace_bytes", "sage_linear_act_backward_ws",
+    "sage_gather_mean_backward_workspace_bytes", "sage_gather_mean_backward_ws",
     "sage_prepared_weight_bytes", "sage_prepare_weights",
     "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_profiled", "sage_pipe_submit_many",
-    "sage_pipe_join", "sage_pipe_fork",
+    "sage_pipe_join", "sage_pipe_fork", "sage_pipe_reset",
 ]
 PIPE_MAX_DEPTH = 8
 
@@ -112,6 +114,11 @@ def lib():
     L.sage_linear_act_backward.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
                                            P, I64, P, I64, P]
     L.sage_gather_mean_backward.argtypes = [P, I64, I32, P, P, I32, I32, P, P, P, P, I64, I64, P]
+    L.sage_linear_act_backward_workspace_bytes.argtypes = [I32, I32, I32, I32]
+    L.sage_linear_act_backward_ws.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
+                                              P, I64, P, I64, P, c_size_t, P]
+    L.sage_gather_mean_backward_workspace_bytes.argtypes = [I32, I32, I64]
+    L.sage_gather_mean_backward_ws.argtypes = [P, I64, I32, P, P, I32, I32, P, P, P, P, I64, P, I64, P, c_size_t, P]
     L.sage_prepared_weight_bytes.argtypes = [I32, I32, I32]
     L.sage_prepare_weights.argtypes = [P, I64, I32, I32, I32, P, c_size_t, P]
     L.sage_pipe_create.argtypes = [POINTER(Model), I32, I32, POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_void_p)]
@@ -122,9 +129,10 @@ def lib():
     L.sage_pipe_submit_many.argtypes = [P, P, I64, POINTER(c_uint64), I32, P, I64, I64, I32, I32]
     L.sage_pipe_join.argtypes = [P, P]
     L.sage_pipe_fork.argtypes = [P, P]
+    L.sage_pipe_reset.argtypes = [P]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name == "sage_prepared_weight_bytes":
+        if name == "sage_prepared_weight_bytes" or name.endswith("_workspace_bytes"):
             fn.restype = c_size_t
         elif name not in ("sage_last_error", "sage_build_arch"):
             fn.restype = c_int32

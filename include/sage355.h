@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 2
+#define SAGE_ABI_VERSION 3
 
 #define SAGE_OK            0
 #define SAGE_EINVAL       -1   /* bad argument (NULL, size, alignment, range) */
@@ -194,6 +194,34 @@ int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int32_t dim,
                               float* grad_table, int64_t table_rows, int64_t ld,
                               sage_stream_t stream);
 
+/* Reproducible forms (ABI 3).  torch autograd on the reference's CPU (model.py:249) gives the same bits run after run; the two
+ * entry points above add in order of arrival (fp32 atomics).  These take a caller-owned workspace instead and are bitwise
+ * reproducible for given inputs and launch tunables:
+ *  - sage_linear_act_backward_ws: the reduction over the n rows is cut into row ranges, every range STORES its partial
+ *    [out_dim, ds+dim] tile in the workspace, one kernel adds the partials in range order to grad_weight (still "+=": the
+ *    caller zeroes).  grad_x as above.  Even widths / leading dimensions and 8-byte aligned arrays take the fast kernel (operands
+ *    straight from HBM in MFMA register order); anything else the generic tile kernel, also through partials.
+ *  - sage_gather_mean_backward_ws: an inverted index (expand -> stable radix sort by table row -> run heads) built per call in
+ *    the workspace; every table row's terms are then summed in ascending (r, j) order and the row is STORED (zeros where
+ *    nobody points): rows [0, min(*table_rows_dev, table_rows)) of grad_table are written, the caller zeroes nothing.
+ *    Needs dim % 4 == 0, ld % 4 == 0, 16-byte aligned arrays.
+ * The *_workspace_bytes queries are host-side arithmetic (0 = shape out of range / query failed); workspaces 256-byte aligned. */
+size_t sage_linear_act_backward_workspace_bytes(int32_t n, int32_t dim, int32_t has_self, int32_t out_dim);
+int sage_linear_act_backward_ws(const float* self_tab, int64_t ld_self, const int32_t* self_index,
+                                const float* agg, int64_t ld_agg, int32_t dim,
+                                const float* weight, int64_t ldw, int32_t out_dim, int32_t act,
+                                const float* out, int64_t ldo, const float* grad_out, int64_t ldg,
+                                int32_t n, const int32_t* n_dev,
+                                float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                                void* workspace, size_t workspace_bytes, sage_stream_t stream);
+size_t sage_gather_mean_backward_workspace_bytes(int32_t n, int32_t k, int64_t table_rows);
+int sage_gather_mean_backward_ws(const float* grad_agg, int64_t ldg, int32_t dim,
+                                 const int32_t* nbr, const int32_t* cnt, int32_t k,
+                                 int32_t n, const int32_t* n_dev,
+                                 const int32_t* slot_rows, const int32_t* self_row,
+                                 float* grad_table, int64_t table_rows, const int32_t* table_rows_dev, int64_t ld,
+                                 void* workspace, size_t workspace_bytes, sage_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Two-layer forward: model.py:219-222 wiring of two Encoders, i.e. the
  * "2-hop forward" the headline metric counts.
@@ -322,10 +350,14 @@ int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t 
  * hipEvents; workspaces (each laid out by sage_forward2_layout and initialised by
  * sage_forward2_init for m->ws_batch / `batch`), streams and outputs belong to the caller.
  * streams[4] = {S, G, D, L}; entries may coincide (the event between two roles on one stream is
- * skipped).  All calls are host-side enqueues (eleven stream operations per batch).  Capturing the four-stream
- * pattern into ONE hipGraph (fork -> submits -> join) crashes inside hipStreamEndCapture on ROCm 7.2
- * (experiments/pipe_sweep.py, SWEEP_GRAPH=1), so the pipe is driven eagerly; sage_pipe_fork / sage_pipe_join
- * order it against the caller's own stream.  Not thread safe per pipe.
+ * skipped).  All calls are host-side enqueues (eleven stream operations per batch); sage_pipe_fork / sage_pipe_join
+ * order the pipe against the caller's own stream.  The whole pattern -- hipStreamBeginCapture(stream), sage_pipe_fork(stream),
+ * submits (the first `depth` of them on free workspaces: segment_start, or sage_pipe_reset before), sage_pipe_join(stream),
+ * hipStreamEndCapture -- can be captured into ONE hipGraph (ABI 3): while the role streams are capturing, the workspace-release
+ * edge L(b) -> S(b + depth) is added as an explicit node dependency, because waiting for it by event crashes
+ * hipStreamEndCapture on ROCm 7.2 (csrc/sage_pipe.hip, experiments/r03/capture_repro.cpp).  The captured graph embeds the seeds
+ * pointers and keys of the batches it was captured with.  After a capture, call sage_pipe_reset before eager submission.
+ * Not thread safe per pipe.
  * Replaces nothing in the reference (model.py:240-252 runs one batch at a time).
  * ------------------------------------------------------------------------- */
 #define SAGE_PIPE_MAX_DEPTH 8
@@ -350,6 +382,8 @@ int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64_t seed_str
 /* `stream` waits for everything submitted so far / every role stream waits for `stream`. */
 int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream);
 int sage_pipe_fork(sage_pipe_t* p, sage_stream_t stream);
+/* Forget every submit (the next `depth` submits find their workspaces free); the caller has joined / synchronised all of them. */
+int sage_pipe_reset(sage_pipe_t* p);
 
 #ifdef __cplusplus
 }

@@ -47,3 +47,16 @@ def assert_close_rowmax(actual, expected, rtol=RTOL, rows_dim=0, what=""):
     err = ((a - e).abs() / scale).max().item()
     assert err <= rtol, f"{what}: max |a-b|/rowmax = {err:.3e} > {rtol:.1e}"
     return err
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask / cgroup quota, not the machine's core count (a GPU box
+    reports 256 cores to a 16-core share, and torch's CPU ops on 256 intra-op threads run 20x slower there than on 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
