@@ -66,9 +66,11 @@ def parse():
                     help="device layout the engine builds from the caller's graph: degree = rows sorted by descending degree "
                          "(TwoHopEngine(relabel='degree'): the most-gathered feature rows are neighbours in HBM; seeds keep the "
                          "caller's ids and are translated by the outer-hop kernel inside every forward); input = the caller's order")
-    ap.add_argument("--exec", choices=["pipe", "replay", "direct"], default=os.environ.get("SAGE_EXEC", "pipe"),
-                    help="pipe: RolePipeline (stages on role streams); replay: hipGraph replay from a device batch queue, "
-                         "--streams forwards in flight; direct: host-enqueued forwards")
+    ap.add_argument("--exec", choices=["pipe", "pipegraph", "replay", "direct"], default=os.environ.get("SAGE_EXEC", "pipe"),
+                    help="pipe: RolePipeline (stages on role streams), one host call per batch; pipegraph: the same role pipeline with the "
+                         "W warm-up batches and the K timed batches each captured as ONE hipGraph over the four role streams (one graph "
+                         "launch per region); replay: hipGraph replay from a device batch queue, --streams forwards in flight; direct: "
+                         "host-enqueued forwards")
     ap.add_argument("--preheat-seconds", type=float, default=float(os.environ.get("SAGE_PREHEAT", "0.5")),
                     help="untimed forwards on throw-away batches BEFORE the W warm-up steps, until this much time has passed: a GPU that "
                          "sat idle while the host built the inputs needs tens of ms of load to reach its sustained clocks (measured: the "
@@ -296,10 +298,17 @@ def main():
         exec_mode = "replay"        # 256-seed batches: 20 us of GPU work per batch, less than the host's enqueue per batch
     pipe = None
     engines, streams, outs = [], [], []
-    if exec_mode == "pipe":
+    pipe_graphs = None
+    if exec_mode in ("pipe", "pipegraph"):
         pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, **ekw)
         pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
         torch.cuda.synchronize()
+        if exec_mode == "pipegraph":
+            # fork -> K submits -> join captured once per region; the graphs embed the seeds pointers and keys of their batches
+            gw, cap_stream = pipe.capture(seeds_dev[:args.warmup], sampler_seed[:args.warmup], pipe_out) if args.warmup > 0 else (None, None)
+            gt, cap_stream = pipe.capture(seeds_dev[args.warmup:], sampler_seed[args.warmup:], pipe_out, stream=cap_stream)
+            pipe_graphs = (gw, gt, cap_stream)
+            torch.cuda.synchronize()
     else:
         engines = [base] + [base.sibling() for _ in range(nstreams - 1)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
@@ -320,6 +329,12 @@ def main():
             torch.cuda.synchronize()
 
     def run(step_range):
+        if pipe_graphs is not None:
+            g_ = pipe_graphs[0] if step_range.start == 0 else pipe_graphs[1]
+            if g_ is not None:
+                with torch.cuda.stream(pipe_graphs[2]):
+                    g_.replay()
+            return
         if pipe is not None:
             # one host call per batch (11 enqueues each): measured 2-3 us per forward FASTER than handing all K batches to the
             # C loop at once (sage_pipe_submit_many), whose only difference is that the host runs further ahead of the GPU
@@ -385,7 +400,9 @@ def main():
     #      (the last timed step) against the oracle-gated single forward of the same (seeds, key), bit for bit ----
     timed_check = None
     if gate_out is not None:
-        if pipe is not None:
+        if pipe_graphs is not None:
+            got = pipe_out[(gate_i - args.warmup) % pipe_out.shape[0]]      # the timed graph numbers its batches from 0
+        elif pipe is not None:
             got = pipe_out[gate_i % pipe_out.shape[0]]
         elif exec_mode == "replay" and bpr > 1:
             got = engines[(gate_i // bpr) % nstreams]._graph_out[gate_i % bpr]
@@ -599,6 +616,8 @@ def main():
     if rank == 0:
         if was_pipe:
             execution = f"role pipeline {args.roles} (stages S/G/D/L on HIP streams, hipEvent hand-offs), {args.depth} batches in flight"
+            if exec_mode == "pipegraph":
+                execution += f"; the {args.steps} timed batches captured as ONE hipGraph over the role streams (one graph launch per timed region)"
         elif exec_mode == "replay":
             execution = f"hipGraph replay from a device batch queue, {nstreams} forwards in flight"
         else:

@@ -324,3 +324,43 @@ def test_training_schedule_is_bitwise_reproducible_and_capture_equals_eager(gcn,
     for name, a, c in zip(("w1", "w2", "w_cls"), cap.parameters(), t1.parameters()):
         assert torch.equal(a, c), f"{name}: captured and eager steps differ"
     assert l1[-1] < l1[0]
+
+
+# ------------------------------------------------------------------------------------------ the role pipeline as ONE hipGraph
+@pytest.mark.parametrize("roles,depth,concat", [("SGDL", 4, False), ("SGDD", 3, True), ("SGDL", 2, False)])
+def test_role_pipeline_captured_as_one_graph_replays_bit_identically(roles, depth, concat):
+    """fork -> submits -> join over the four role streams captured into one hipGraph (RolePipeline.capture): replayed, every batch
+    equals the single-stream forward bit for bit, workspaces are reused inside the graph (3 * depth + 1 batches), a second replay
+    gives the same, and eager submission works again afterwards.  The workspace-release edge is an explicit capture dependency
+    (csrc/sage_pipe.hip: waiting for it by event crashes hipStreamEndCapture on ROCm 7.2)."""
+    graph = rmat_graph(15, 600_000, seed=2, accel=None)
+    gen = torch.Generator().manual_seed(0)
+    m = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, 256, generator=gen).to(DEV)
+    w1 = (torch.randn(128, m * 256, generator=gen) / np.sqrt(m * 256)).to(DEV)
+    w2 = (torch.randn(64, m * 128, generator=gen) / np.sqrt(m * 128)).to(DEV)
+    rowptr, col = graph.to(DEV)
+    b, k1, k2 = 1024, 15, 25
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    rs = np.random.default_rng(5)
+    nb = 3 * depth + 1
+    seeds = torch.from_numpy(np.stack([rs.choice(cand, b, replace=False) for _ in range(nb)]).astype(np.int32)).to(DEV)
+    keys = [1000 + i for i in range(nb)]
+    eng = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, concat=concat)
+    want = [eng.forward(seeds[i], seed=keys[i]).clone() for i in range(nb)]
+    pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=depth, roles=roles, concat=concat)
+    out = torch.zeros(nb, b, 64, device=DEV)
+    g, st = pipe.capture(seeds, keys, out)
+    for rep in range(2):
+        out.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            g.replay()
+        torch.cuda.synchronize()
+        for i in range(nb):
+            assert torch.equal(out[i], want[i]), f"replay {rep}, batch {i}: the captured pipeline differs from the single forward"
+    out.zero_()
+    pipe.submit_many(seeds[:depth + 1], keys[:depth + 1], out)           # eager again after the capture
+    pipe.synchronize()
+    for i in range(depth + 1):
+        assert torch.equal(out[i], want[i])
