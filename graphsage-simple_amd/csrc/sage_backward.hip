@@ -21,9 +21,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BM = 64, BN = 128, BK = 32, LDP = BK + 1;
 
-struct Dz {   // dZ(m, h) = grad_out[m, h] * act'(out[m, h])
-    const float* out; int64_t ldo; const float* gout; int64_t ldg; int act;
+struct Dz {   // dZ(m, h) = grad_out[row(m), h] * act'(out[row(m), h]); row(m) = order ? order[m] : m (grad_W's canonical row order)
+    const float* out; int64_t ldo; const float* gout; int64_t ldg; int act; const int32_t* order;
     __device__ float operator()(int m, int h) const {
+        if (order) m = order[m];
         const float g = gout[(int64_t)m * ldg + h];
         const float y = out[(int64_t)m * ldo + h];
         if (act == SAGE_ACT_RELU) return y > 0.f ? g : 0.f;
@@ -32,9 +33,10 @@ struct Dz {   // dZ(m, h) = grad_out[m, h] * act'(out[m, h])
     }
 };
 
-struct Xcat {  // X(m, j) = [self | agg](m, j), the forward's operand (encoders.py:49-56)
-    const float* self_tab; int64_t ld_self; const int32_t* self_index; const float* agg; int64_t ld_agg; int ds;
+struct Xcat {  // X(m, j) = [self | agg](row(m), j), the forward's operand (encoders.py:49-56)
+    const float* self_tab; int64_t ld_self; const int32_t* self_index; const float* agg; int64_t ld_agg; int ds; const int32_t* order;
     __device__ float operator()(int m, int j) const {
+        if (order) m = order[m];
         if (j < ds) {
             const int64_t sr = self_index ? (int64_t)self_index[m] : (int64_t)m;
             return self_tab[sr * ld_self + j];
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256) void bwd_gemm_kernel(Dz dz, Xcat x, const floa
 struct DwArgs {
     const float* gout; int64_t ldg; const float* out; int64_t ldo; int act;     // dZ(k, m) = gout[k][m] * act'(out[k][m])
     const float* x; int64_t ldx; const int32_t* index; int x_rows;              // X(k, n) = x[index ? index[k] : k][n]
+    const int32_t* order;                                                       // nullable: the k-th term of the sum is row order[k]
     int M, Nx, n_rows; const int32_t* rows_dev;
     float* partial; int64_t ldp; int col_off; int nsplit;                       // partial[split][m][col_off + n]
 };
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(512) void bwd_dw_direct_kernel(const DwArgs a) {
         f32x2 g[PF], y[PF], xv[PF];
 #pragma unroll
         for (int p = 0; p < PF; ++p) {                                    // rows past the range: clamped address, zeroed below
-            const int rc = min(k0 + 2 * p + h, kend - 1);
+            int rc = min(k0 + 2 * p + h, kend - 1);
+            if (a.order) rc = a.order[rc];
             int64_t xr = rc;
             if (INDEXED) xr = min(max(a.index[rc], 0), a.x_rows - 1);
             g[p] = *reinterpret_cast<const f32x2*>(gp + (int64_t)rc * a.ldg);
@@ -306,7 +310,7 @@ int linear_act_backward_impl(const float* self_tab, int64_t ld_self, const int32
                              int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
                              int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
                              const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
-                             void* workspace, size_t workspace_bytes, bool reproducible, sage_stream_t stream) {
+                             const int32_t* row_order, void* workspace, size_t workspace_bytes, bool reproducible, sage_stream_t stream) {
     SAGE_REQUIRE(agg && weight && out && grad_out, "linear_act_backward: NULL array");
     SAGE_REQUIRE(n >= 0 && dim >= 1 && out_dim >= 1, "linear_act_backward: n = %d, dim = %d, out_dim = %d", n, dim, out_dim);
     SAGE_REQUIRE(act >= 0 && act <= SAGE_ACT_NONE, "linear_act_backward: act = %d", act);
@@ -322,8 +326,10 @@ int linear_act_backward_impl(const float* self_tab, int64_t ld_self, const int32
     }
     if (n == 0) return SAGE_OK;
     hipStream_t st = (hipStream_t)stream;
-    const Dz dz{out, ldo, grad_out, ldg, act};
-    const Xcat x{self_tab, ld_self, self_index, agg, ld_agg, ds};
+    const Dz dz{out, ldo, grad_out, ldg, act, nullptr};
+    const Xcat x{self_tab, ld_self, self_index, agg, ld_agg, ds, nullptr};
+    const Dz dzo{out, ldo, grad_out, ldg, act, row_order};          // grad_W only: rows in the caller's canonical order
+    const Xcat xo{self_tab, ld_self, self_index, agg, ld_agg, ds, row_order};
     if (grad_x) {
         dim3 grid(sage_cdiv(n, BM), sage_cdiv(K, BN), 1);
         hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1, n_dev, (int64_t)0);
@@ -345,7 +351,7 @@ int linear_act_backward_impl(const float* self_tab, int64_t ld_self, const int32
                         sage_aligned(grad_out, 8) && sage_aligned(out, 8) && sage_aligned(agg, 8) && (!self_tab || sage_aligned(self_tab, 8));
     if (direct) {
         nsplit = dw_direct_splits(n);
-        DwArgs a{grad_out, ldg, out, ldo, act, agg, ld_agg, nullptr, n, out_dim, dim, n, n_dev, partial, ldp, ds, nsplit};
+        DwArgs a{grad_out, ldg, out, ldo, act, agg, ld_agg, nullptr, n, row_order, out_dim, dim, n, n_dev, partial, ldp, ds, nsplit};
         dim3 grid(nsplit, sage_cdiv(dim, 256), sage_cdiv(out_dim, 128));
         hipLaunchKernelGGL(bwd_dw_direct_kernel<false>, grid, dim3(512), 0, st, a);       // the neighbour means: columns [ds, ds + dim)
         SAGE_CHECK_LAUNCH("bwd_dw_direct_kernel<agg>");
@@ -362,7 +368,7 @@ int linear_act_backward_impl(const float* self_tab, int64_t ld_self, const int32
     } else {
         nsplit = dw_generic_splits(n, out_dim, K);
         dim3 grid(sage_cdiv(out_dim, BM), sage_cdiv(K, BN), nsplit);
-        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dz, x, weight, ldw, out_dim, K, n, partial, ldp, nsplit, n_dev,
+        hipLaunchKernelGGL(bwd_gemm_kernel<1>, grid, dim3(256), 0, st, dzo, xo, weight, ldw, out_dim, K, n, partial, ldp, nsplit, n_dev,
                            (int64_t)out_dim * ldp);
         SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_w partials>");
     }
@@ -385,16 +391,16 @@ extern "C" int sage_linear_act_backward(const float* self_tab, int64_t ld_self, 
                                         const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
                                         sage_stream_t stream) {
     return linear_act_backward_impl(self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw, out_dim, act, out, ldo, grad_out, ldg, n,
-                                    n_dev, grad_weight, ldgw, grad_x, ldgx, nullptr, 0, false, stream);
+                                    n_dev, grad_weight, ldgw, grad_x, ldgx, nullptr, nullptr, 0, false, stream);
 }
 
 extern "C" int sage_linear_act_backward_ws(const float* self_tab, int64_t ld_self, const int32_t* self_index, const float* agg,
                                            int64_t ld_agg, int32_t dim, const float* weight, int64_t ldw, int32_t out_dim,
                                            int32_t act, const float* out, int64_t ldo, const float* grad_out, int64_t ldg, int32_t n,
                                            const int32_t* n_dev, float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
-                                           void* workspace, size_t workspace_bytes, sage_stream_t stream) {
+                                           const int32_t* row_order, void* workspace, size_t workspace_bytes, sage_stream_t stream) {
     return linear_act_backward_impl(self_tab, ld_self, self_index, agg, ld_agg, dim, weight, ldw, out_dim, act, out, ldo, grad_out, ldg, n,
-                                    n_dev, grad_weight, ldgw, grad_x, ldgx, workspace, workspace_bytes, true, stream);
+                                    n_dev, grad_weight, ldgw, grad_x, ldgx, row_order, workspace, workspace_bytes, true, stream);
 }
 
 extern "C" int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int32_t dim, const int32_t* nbr, const int32_t* cnt,

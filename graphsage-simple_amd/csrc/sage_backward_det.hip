@@ -144,6 +144,68 @@ __global__ __launch_bounds__(256) void det_sum_kernel(const float* __restrict__ 
 
 }  // namespace
 
+// ---- canonical order of a layer's rows ---------------------------------------------------------------------------------------------
+// The frontier's rows are in ARBITRARY order (whichever lane won the hash slot first, aggregators.py:52: a Python set's order is
+// arbitrary too), so a sum over the layer's rows -- the weight gradient -- adds in a different order run after run.  Nothing else
+// depends on the order.  order[] lists the live rows canonically: rows [0, first_row) (the concat encoder's own seeds, in seed order)
+// as they are, then the frontier rows by ascending node id (ids are distinct there).  One key per row + a stable radix sort.
+namespace {
+__global__ __launch_bounds__(256) void order_keys_kernel(const int32_t* __restrict__ nodes, int n, const int32_t* __restrict__ n_dev,
+                                                         int first_row, int32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int nn = n;
+    if (n_dev) nn = min(*n_dev, n);
+    const int64_t key = r < first_row ? (int64_t)r : (int64_t)first_row + (int64_t)max(nodes[r], 0);
+    keys[r] = r < nn ? (int32_t)min(key, (int64_t)0x7FFFFFFE) : 0x7FFFFFFF;      // dead rows sort to the end
+    vals[r] = r;
+}
+struct OrderLayout { size_t keys_in, keys_out, vals_in, cub, total, cub_bytes; };
+bool order_layout(int n, OrderLayout* L) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    L->keys_in = take((size_t)n * 4);
+    L->keys_out = take((size_t)n * 4);
+    L->vals_in = take((size_t)n * 4);
+    if (sort_temp_bytes(n, 31, &L->cub_bytes) != hipSuccess) return false;
+    L->cub = take(L->cub_bytes + 16);
+    L->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t sage_row_order_workspace_bytes(int32_t n) {
+    if (n <= 0) return 0;
+    OrderLayout L;
+    return order_layout(n, &L) ? L.total : 0;
+}
+
+extern "C" int sage_row_order(const int32_t* nodes, int32_t n, const int32_t* n_dev, int32_t first_row, int32_t* order,
+                              void* workspace, size_t workspace_bytes, sage_stream_t stream) {
+    SAGE_REQUIRE(nodes && order && workspace && sage_aligned(workspace, 256), "row_order: NULL / unaligned argument");
+    SAGE_REQUIRE(n >= 1 && first_row >= 0 && first_row <= n, "row_order: n = %d, first_row = %d", n, first_row);
+    OrderLayout L;
+    SAGE_REQUIRE(order_layout(n, &L), "row_order: radix sort size query failed");
+    if (L.total > workspace_bytes) {
+        sage_set_error("row_order: workspace %zu bytes < %zu needed", workspace_bytes, L.total);
+        return SAGE_ENOSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int32_t* keys_in = (int32_t*)(ws + L.keys_in);
+    int32_t* keys_out = (int32_t*)(ws + L.keys_out);
+    int32_t* vals_in = (int32_t*)(ws + L.vals_in);
+    hipLaunchKernelGGL(order_keys_kernel, dim3(sage_cdiv(n, 256)), dim3(256), 0, st, nodes, n, n_dev, first_row, keys_in, vals_in);
+    SAGE_CHECK_LAUNCH("order_keys_kernel");
+    size_t cub_bytes = L.cub_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int32_t*)keys_in, keys_out, (const int32_t*)vals_in, order, n, 0, 31, st) !=
+        hipSuccess) {
+        sage_set_error("row_order: radix sort failed");
+        return SAGE_ELAUNCH;
+    }
+    return SAGE_OK;
+}
+
 extern "C" size_t sage_gather_mean_backward_workspace_bytes(int32_t n, int32_t k, int64_t table_rows) {
     if (n <= 0 || k <= 0 || table_rows <= 0 || table_rows >= (1ll << 31) || (int64_t)n * (k + 1) >= (1ll << 31)) return 0;
     DetLayout L;

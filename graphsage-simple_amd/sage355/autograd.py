@@ -58,7 +58,7 @@ class _LinearAct(torch.autograd.Function):
             native.ptr(agg), agg.stride(0), dim, native.ptr(weight), weight.stride(0), out_dim, int(ctx.act),
             native.ptr(out), out.stride(0), native.ptr(grad_out), grad_out.stride(0), n, None,
             native.ptr(grad_w), grad_w.stride(0) if grad_w is not None else 0,
-            native.ptr(grad_x), grad_x.stride(0) if grad_x is not None else 0,
+            native.ptr(grad_x), grad_x.stride(0) if grad_x is not None else 0, None,
             native.ptr(ws), ws.numel() if ws is not None else 0, native.stream_handle())
         native.check(rc, "linear_act_backward")
         grad_agg = grad_self = None

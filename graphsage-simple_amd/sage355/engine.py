@@ -359,7 +359,7 @@ class TwoHopEngine:
         ws2 = scratch("ws_dw2", lib.sage_linear_act_backward_workspace_bytes(b, h1p, int(self.concat), self.h2))
         native.check(lib.sage_linear_act_backward_ws(P(h1) if self.concat else None, h1p, None, P(agg2), agg2.stride(0), h1p, P(w2p),
                                                      w2p.stride(0), self.h2, self.act2, P(out), out.stride(0), P(grad_out), grad_out.stride(0), b, None,
-                                                     P(g_w2p), g_w2p.stride(0), P(g_x2) if need_w1 else None, g_x2.stride(0),
+                                                     P(g_w2p), g_w2p.stride(0), P(g_x2) if need_w1 else None, g_x2.stride(0), None,
                                                      P(ws2), ws2.numel(), st), "linear_act_backward (layer 2)")
         g_w1p = None
         if need_w1:
@@ -386,11 +386,17 @@ class TwoHopEngine:
                 ops.gather_mean(self.table, nbr1, cnt1, self_row=self_row1, any_nonempty=sc["any"], n_dev=sc["nlive"], out=sc["agg1"])
                 agg1 = sc["agg1"]
             g_w1p = torch.zeros_like(w1p)
+            # the frontier's rows are in arbitrary order (who won which hash slot first): the sum over them runs in a canonical
+            # order -- the seeds' own rows, then the frontier by node id -- so that the gradient does not depend on the layout
+            if sc.get("order") is None or sc["order"].numel() != L.max_s1:
+                sc["order"] = torch.empty(L.max_s1, dtype=torch.int32, device=dev)
+            wso = scratch("ws_order", lib.sage_row_order_workspace_bytes(L.max_s1))
+            native.check(lib.sage_row_order(P(s1_nodes), L.max_s1, P(sc["nlive"]), first, P(sc["order"]), P(wso), wso.numel(), st), "row_order")
             ws1 = scratch("ws_dw1", lib.sage_linear_act_backward_workspace_bytes(L.max_s1, d0p, int(self.concat), h1p))
             native.check(lib.sage_linear_act_backward_ws(P(self.table) if self.concat else None, self.table_ld, P(s1_nodes) if self.concat else None,
                                                          P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, self.act1, P(h1), h1p,
                                                          P(sc["grad_h1"]), h1p, L.max_s1, P(sc["nlive"]), P(g_w1p), g_w1p.stride(0), None, 0,
-                                                         P(ws1), ws1.numel(), st),
+                                                         P(sc["order"]), P(ws1), ws1.numel(), st),
                          "linear_act_backward (layer 1)")
         # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
         if self._padded:

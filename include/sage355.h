@@ -213,7 +213,16 @@ int sage_linear_act_backward_ws(const float* self_tab, int64_t ld_self, const in
                                 const float* out, int64_t ldo, const float* grad_out, int64_t ldg,
                                 int32_t n, const int32_t* n_dev,
                                 float* grad_weight, int64_t ldgw, float* grad_x, int64_t ldgx,
+                                const int32_t* row_order /* nullable */,
                                 void* workspace, size_t workspace_bytes, sage_stream_t stream);
+/* The frontier's rows are in arbitrary order (aggregators.py:52: so is a Python set), and the weight gradient is a sum over the
+ * layer's rows: for the same bits run after run it has to add them in an order that does not depend on the layout.  sage_row_order
+ * writes that order -- rows [0, first_row) as they are (the concat encoder's own seeds), then the live rows [first_row, *n_dev) by
+ * ascending node id (distinct there), dead rows last -- and sage_linear_act_backward_ws(row_order = it) sums its k-th term from row
+ * row_order[k] (grad_weight only; grad_x is per row).  nodes: int32[n], the layer's node ids (sage_ws_layout_t.s1_nodes). */
+size_t sage_row_order_workspace_bytes(int32_t n);
+int sage_row_order(const int32_t* nodes, int32_t n, const int32_t* n_dev, int32_t first_row, int32_t* order,
+                   void* workspace, size_t workspace_bytes, sage_stream_t stream);
 size_t sage_gather_mean_backward_workspace_bytes(int32_t n, int32_t k, int64_t table_rows);
 int sage_gather_mean_backward_ws(const float* grad_agg, int64_t ldg, int32_t dim,
                                  const int32_t* nbr, const int32_t* cnt, int32_t k,
