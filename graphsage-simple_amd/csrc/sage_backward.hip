@@ -163,6 +163,7 @@ struct DwArgs {
 };
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <bool INDEXED>
 __global__ __launch_bounds__(512) void bwd_dw_direct_kernel(const DwArgs a) {
@@ -299,6 +300,183 @@ __global__ __launch_bounds__(256) void gather_mean_bwd_kernel(const float* __res
 }  // namespace
 
 namespace {
+// ---- layer-1 weight gradient of the two-layer stack, summed over the OUTER EDGES (round 3) -------------------------------------------
+// d loss / d W1 = sum over the layer-1 rows t of dZ1[t] (x) X1[t], dZ1[t] = act'(h1[t]) . grad_h1[t], and grad_h1[t] is the mean
+// backward of layer 2: the sum over the outer samples e = (seed r, slot j) that point at row t of grad_agg2[r] / c_r.  Written as a sum
+// over ROWS this needs grad_h1 (a scatter: atomics, or an inverted index = a device-wide sort per step) and, for reproducible bits,
+// a canonical order of the frontier's rows, which sit in arbitrary order (a second sort).  Re-associated as a sum over the EDGES,
+//     d W1 = sum_r [ concat: act'(h1[r]) . g_self[r] (x) X1[r] ]  +  sum_r sum_{j < c_r} (act'(h1[t_rj]) . g_agg[r] / c_r) (x) X1[t_rj],
+// the terms come in (r, j) order -- fixed by the seeds and the sampler key, whatever the frontier's layout -- and neither grad_h1, nor
+// the scatter, nor any sort exists: 1.7x the matrix work of the row form (an edge per term instead of a row per term) against five
+// launches and ~140 us less at config 3.  Bitwise reproducible: a block owns a fixed range of seeds, compacts their live terms in
+// slot order (ballot prefix in LDS), stages 16 terms at a time -- dZ [16 x 128] and X1 [16 x 256], gathered by 16-byte pieces,
+// double-buffered in LDS, the next trip's rows in flight during the MFMA loop -- and STORES its partial tile for dw_reduce_kernel.
+struct EdgeArgs {
+    const float* gx2; int64_t ldgx; int g_self_off, g_agg_off;      // layer 2's grad_x: columns of the self part (concat) / the mean part
+    const int32_t* row2; const int32_t* cnt2; int k2; const int32_t* self_row2; int batch;
+    const float* h1; int64_t ldh; int M; int act;                    // layer-1 output rows (M = its width) and activation
+    const float* agg1; int64_t lda; int d0;
+    const float* table; int64_t table_ld; const int32_t* s1_nodes; int concat;
+    float* partial; int64_t ldp; int rows_per_chunk;
+};
+
+constexpr int EK_KT = 16, EK_TMAX = 512, EK_LDZ = 128 + 4, EK_LDX = 256 + 4, EK_ROWS = 64;
+
+__global__ __launch_bounds__(512) void bwd_dw_edges_kernel(const EdgeArgs a) {
+    __shared__ int term_t[EK_TMAX + EK_KT], term_r[EK_TMAX + EK_KT], term_g[EK_TMAX + EK_KT], term_s[EK_TMAX + EK_KT];
+    __shared__ float term_w[EK_TMAX + EK_KT];
+    __shared__ __attribute__((aligned(16))) float dzs[2][EK_KT][EK_LDZ];
+    __shared__ __attribute__((aligned(16))) float xs[2][EK_KT][EK_LDX];
+    __shared__ int rowc[EK_ROWS], rowx[EK_ROWS], wcount[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int SPR = a.k2 + 2;                                       // slots per seed: own row (concat), k2 samples, the self-loop row
+    const int m0b = blockIdx.z * 128, n0b = blockIdx.y * 256;
+    const int mrel = (wave >> 2) * 64, nrel = (wave & 3) * 64;
+    const int ds = a.concat ? a.d0 : 0, K1 = ds + a.d0;
+    const int i = lane & 31, h = lane >> 5;
+    const bool wave_live = m0b + mrel < a.M && n0b + nrel < K1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    // staging duty of this thread: one 16-byte piece of dZ (term tid / 32, columns 4 (tid % 32)), two of X1
+    const int zk = tid >> 5, zc = m0b + 4 * (tid & 31);
+    const bool zok = zc < a.M;
+    const int RB = a.rows_per_chunk;
+    const int nchunks = (a.batch + RB - 1) / RB;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int r_beg = chunk * RB, nrows = min(RB, a.batch - r_beg);
+        __syncthreads();                                            // the previous chunk's last trip has been read
+        if (tid < nrows) {
+            const int r = r_beg + tid;
+            const int c = min(max(a.cnt2[r], 0), a.k2);
+            int s = a.self_row2 ? a.self_row2[r] : -1;
+            if (s >= 0)
+                for (int j = 0; j < c; ++j)
+                    if (a.row2[(int64_t)r * a.k2 + j] == s) { s = -1; break; }      // aggregators.py:50-51: set union (the forward's rule)
+            rowc[tid] = c;
+            rowx[tid] = s;
+        }
+        __syncthreads();
+        int base = 0;
+        for (int s0 = 0; s0 < nrows * SPR; s0 += 512) {              // slots -> live terms, in slot order
+            const int sl = s0 + tid;
+            bool valid = false;
+            int t = 0, r = r_beg, g = a.g_agg_off;
+            float w = 0.f;
+            if (sl < nrows * SPR) {
+                const int lr = sl / SPR, j = sl % SPR;
+                r = r_beg + lr;
+                const int c = rowc[lr], ex = rowx[lr];
+                const float inv = 1.0f / (float)max(c + (ex >= 0 ? 1 : 0), 1);
+                if (j == 0) { if (a.concat) { valid = true; t = r; w = 1.f; g = a.g_self_off; } }
+                else if (j <= a.k2) { if (j - 1 < c) { valid = true; t = a.row2[(int64_t)r * a.k2 + j - 1]; w = inv; } }
+                else if (ex >= 0) { valid = true; t = ex; w = inv; }
+                if (t < 0) valid = false;
+            }
+            const unsigned long long b = __ballot(valid);
+            if (lane == 0) wcount[wave] = __popcll(b);
+            __syncthreads();
+            int off = base;
+            for (int q = 0; q < wave; ++q) off += wcount[q];
+            int total = 0;
+            for (int q = 0; q < 8; ++q) total += wcount[q];
+            if (valid) {
+                const int pos = off + __popcll(b & ((1ull << lane) - 1ull));
+                term_t[pos] = t; term_r[pos] = r; term_g[pos] = g; term_w[pos] = w;
+                term_s[pos] = (a.concat && a.s1_nodes) ? a.s1_nodes[t] : t;
+            }
+            base += total;
+            __syncthreads();
+        }
+        const int nterm = (base + EK_KT - 1) / EK_KT * EK_KT;
+        if (tid < nterm - base) {                                   // pad the last trip with weight-0 terms on a valid row
+            const int pos = base + tid;
+            term_t[pos] = 0; term_r[pos] = r_beg; term_g[pos] = a.g_agg_off; term_w[pos] = 0.f; term_s[pos] = (a.concat && a.s1_nodes) ? a.s1_nodes[0] : 0;
+        }
+        __syncthreads();
+        f32x4 gq, yq, xq[2];
+        auto request = [&](int trip) {                               // global -> registers, no wait
+            const int kk = trip * EK_KT + zk;
+            const int t = term_t[kk], r = term_r[kk];
+            const int zcl = min(zc, a.M - 4);
+            gq = *reinterpret_cast<const f32x4*>(a.gx2 + (int64_t)r * a.ldgx + term_g[kk] + zcl);
+            yq = *reinterpret_cast<const f32x4*>(a.h1 + (int64_t)t * a.ldh + zcl);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 512 * u, xk = trip * EK_KT + (idx >> 6);
+                const int n = min(n0b + 4 * (idx & 63), K1 - 4);
+                const float* src = (n < ds) ? a.table + (int64_t)term_s[xk] * a.table_ld + n : a.agg1 + (int64_t)term_t[xk] * a.lda + (n - ds);
+                xq[u] = *reinterpret_cast<const f32x4*>(src);
+            }
+        };
+        auto stage = [&](int buf, int trip) {                        // registers -> LDS
+            const float w = term_w[trip * EK_KT + zk];
+            f32x4 dz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = gq[e];
+                if (a.act == SAGE_ACT_RELU) v = yq[e] > 0.f ? v : 0.f;
+                else if (a.act == SAGE_ACT_SIGMOID) v = v * yq[e] * (1.f - yq[e]);
+                dz[e] = (zok && w != 0.f) ? v * w : 0.f;             // select: a padded term may sit on a row holding Inf / NaN
+            }
+            *reinterpret_cast<f32x4*>(&dzs[buf][zk][4 * (tid & 31)]) = dz;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 512 * u;
+                const bool nok = n0b + 4 * (idx & 63) < K1;
+                f32x4 xv = xq[u];
+                if (!nok) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&xs[buf][idx >> 6][4 * (idx & 63)]) = xv;
+            }
+        };
+        const int ntrip = nterm / EK_KT;
+        int buf = 0;
+        if (ntrip > 0) request(0);
+        for (int trip = 0; trip < ntrip; ++trip, buf ^= 1) {
+            stage(buf, trip);
+            __syncthreads();
+            if (trip + 1 < ntrip) request(trip + 1);                 // in flight during the MFMA loop
+            if (wave_live) {
+#pragma unroll
+                for (int kp = 0; kp < EK_KT / 2; ++kp) {
+                    const f32x2 av = *reinterpret_cast<const f32x2*>(&dzs[buf][2 * kp + h][mrel + 2 * i]);
+                    const f32x2 bv = *reinterpret_cast<const f32x2*>(&xs[buf][2 * kp + h][nrel + 2 * i]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave_live) {
+        float* P = a.partial + (int64_t)blockIdx.x * a.M * a.ldp;
+        const int nc = n0b + nrel + 2 * i;
+        if (nc < K1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = m0b + mrel + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * h) + e;
+                    if (m < a.M) *reinterpret_cast<f32x2*>(P + (int64_t)m * a.ldp + nc) = f32x2{acc[e][0][reg], acc[e][1][reg]};
+                }
+        }
+    }
+}
+
+int edges_rows_per_chunk(int batch, int k2) {
+    const int cap = max(1, min(EK_ROWS, EK_TMAX / (k2 + 2)));       // a chunk's slots fit the LDS term list (61 KB of LDS per block in all)
+    return max(min(cap, 4), min(cap, sage_cdiv(batch, sage_tunables().bwd_direct_blocks)));   // small batches: >= 4 seeds per chunk (whole trips)
+}
+int edges_splits(int batch, int k2) { return max(1, min(sage_tunables().bwd_direct_blocks, sage_cdiv(batch, edges_rows_per_chunk(batch, k2)))); }
+
+}  // namespace
+
+namespace {
 // splits of the reduction over the rows: the direct kernel's row ranges / the generic kernel's K splits
 int dw_direct_splits(int n) { return max(1, min(sage_tunables().bwd_direct_blocks, sage_cdiv(n, 64))); }
 int dw_generic_splits(int n, int out_dim, int K) {
@@ -415,5 +593,42 @@ extern "C" int sage_gather_mean_backward(const float* grad_agg, int64_t ldg, int
     hipLaunchKernelGGL(gather_mean_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_agg, ldg, dim, nbr, cnt, k, n, n_dev,
                        slot_rows, self_row, grad_table, (int)table_rows, ld);
     SAGE_CHECK_LAUNCH("gather_mean_bwd_kernel");
+    return SAGE_OK;
+}
+
+extern "C" size_t sage_two_hop_grad_w1_workspace_bytes(int32_t batch, int32_t k2, int32_t d0, int32_t concat, int32_t h1) {
+    if (batch <= 0 || k2 <= 0 || d0 <= 0 || h1 <= 0) return 16;
+    return (size_t)edges_splits(batch, k2) * h1 * ((concat ? 2 : 1) * (size_t)d0) * sizeof(float) + 16;
+}
+
+extern "C" int sage_two_hop_grad_w1(const float* grad_x2, int64_t ldgx, const int32_t* row2, const int32_t* cnt2, int32_t k2,
+                                    const int32_t* self_row2, int32_t batch, const float* h1, int64_t ldh, int32_t h1_dim, int32_t act1,
+                                    const float* agg1, int64_t lda, int32_t d0, int32_t concat, const float* table, int64_t table_ld,
+                                    const int32_t* s1_nodes, float* grad_w1, int64_t ldgw, void* workspace, size_t workspace_bytes,
+                                    sage_stream_t stream) {
+    SAGE_REQUIRE(grad_x2 && row2 && cnt2 && h1 && agg1 && grad_w1 && workspace, "two_hop_grad_w1: NULL array");
+    SAGE_REQUIRE(!concat || (table && s1_nodes), "two_hop_grad_w1: the concat encoder needs the table and the layer's node ids");
+    SAGE_REQUIRE(batch >= 1 && k2 >= 1 && k2 <= SAGE_MAX_FANOUT && act1 >= 0 && act1 <= SAGE_ACT_NONE, "two_hop_grad_w1: batch = %d, k2 = %d", batch, k2);
+    const int mult = concat ? 2 : 1;
+    SAGE_REQUIRE(h1_dim >= 4 && h1_dim % 4 == 0 && d0 >= 4 && d0 % 4 == 0 && ldgx % 4 == 0 && ldh % 4 == 0 && lda % 4 == 0 &&
+                 (!concat || table_ld % 4 == 0) && ldgx >= mult * h1_dim && ldh >= h1_dim && lda >= d0 && ldgw >= mult * d0,
+                 "two_hop_grad_w1: widths and leading dimensions must be multiples of 4 (h1 = %d, d0 = %d)", h1_dim, d0);
+    SAGE_REQUIRE(sage_aligned(grad_x2, 16) && sage_aligned(h1, 16) && sage_aligned(agg1, 16) && (!concat || sage_aligned(table, 16)) &&
+                 sage_aligned(workspace, 16), "two_hop_grad_w1: 16-byte alignment");
+    const size_t need = sage_two_hop_grad_w1_workspace_bytes(batch, k2, d0, concat, h1_dim);
+    if (workspace_bytes < need) {
+        sage_set_error("two_hop_grad_w1: workspace %zu bytes < %zu needed", workspace_bytes, need);
+        return SAGE_ENOSPACE;
+    }
+    const int K1 = mult * d0, nsplit = edges_splits(batch, k2);
+    hipStream_t st = (hipStream_t)stream;
+    const EdgeArgs a{grad_x2, ldgx, 0, concat ? h1_dim : 0, row2, cnt2, k2, self_row2, batch, h1, ldh, h1_dim, act1, agg1, lda, d0,
+                     table, table_ld, s1_nodes, concat ? 1 : 0, (float*)workspace, (int64_t)K1, edges_rows_per_chunk(batch, k2)};
+    dim3 grid(nsplit, sage_cdiv(K1, 256), sage_cdiv(h1_dim, 128));
+    hipLaunchKernelGGL(bwd_dw_edges_kernel, grid, dim3(512), 0, st, a);
+    SAGE_CHECK_LAUNCH("bwd_dw_edges_kernel");
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(sage_cdiv((int64_t)h1_dim * K1, 256)), dim3(256), 0, st, (const float*)workspace, nsplit, h1_dim, K1,
+                       (int64_t)K1, grad_w1, ldgw);
+    SAGE_CHECK_LAUNCH("dw_reduce_kernel");
     return SAGE_OK;
 }

@@ -327,7 +327,7 @@ class TwoHopEngine:
         dev = self.device
         if self._bwd is None or self._bwd["max_s1"] != L.max_s1:
             self._bwd = {"max_s1": L.max_s1, "nlive": torch.zeros(1, dtype=torch.int32, device=dev),
-                         "grad_h1": torch.zeros(L.max_s1, self.h1p, device=dev), "agg1": None,
+                         "agg1": None,
                          "any": torch.ones(1, dtype=torch.int32, device=dev)}
         sc = self._bwd
         first = b if self.concat else 0
@@ -363,19 +363,10 @@ class TwoHopEngine:
                                                      P(ws2), ws2.numel(), st), "linear_act_backward (layer 2)")
         g_w1p = None
         if need_w1:
-            # ---- d h1: every frontier row sums the means it is a member of (rows [0, nlive) are written, nothing is zeroed);
-            #      the concat encoder's own rows are the first B
-            g_agg2 = g_x2[:, (mult - 1) * h1p:]
-            need = lib.sage_gather_mean_backward_workspace_bytes(b, k2, L.max_s1)
-            if need == 0:
-                raise native.SageError("gather_mean_backward_ws: workspace size query failed")
-            wsg = scratch("ws_gm", need)
-            native.check(lib.sage_gather_mean_backward_ws(P(g_agg2), g_x2.stride(0), h1p, P(row2), P(cnt2), k2, b, None, None, P(self_row2),
-                                                          P(sc["grad_h1"]), L.max_s1, P(sc["nlive"]), h1p, P(wsg), wsg.numel(), st),
-                         "gather_mean_backward (layer 2)")
-            if self.concat:
-                sc["grad_h1"][:b] += g_x2[:, :h1p]
-            # ---- layer 1 backward: only dW1 (the table is frozen); agg1 from the workspace (split layer) or recomputed on the live rows
+            # ---- layer 1 backward: only dW1 (the table is frozen), summed over the OUTER EDGES (sage_two_hop_grad_w1): the terms
+            #      act1'(h1[t]) . g_agg2[r] / c_r (x) X1[t] come in (seed, slot) order, so neither grad_h1 (a scatter) nor an order of the
+            #      frontier's arbitrarily placed rows is needed, and the bits do not depend on the layout.  agg1 from the workspace
+            #      (split layer) or recomputed on the live rows
             self_row1 = s1_nodes if self.agg_self_loop else None
             if L.layer1_split:
                 # the split layer (sliced gather + contraction) left the means of this very forward in the workspace: no second gather
@@ -386,18 +377,11 @@ class TwoHopEngine:
                 ops.gather_mean(self.table, nbr1, cnt1, self_row=self_row1, any_nonempty=sc["any"], n_dev=sc["nlive"], out=sc["agg1"])
                 agg1 = sc["agg1"]
             g_w1p = torch.zeros_like(w1p)
-            # the frontier's rows are in arbitrary order (who won which hash slot first): the sum over them runs in a canonical
-            # order -- the seeds' own rows, then the frontier by node id -- so that the gradient does not depend on the layout
-            if sc.get("order") is None or sc["order"].numel() != L.max_s1:
-                sc["order"] = torch.empty(L.max_s1, dtype=torch.int32, device=dev)
-            wso = scratch("ws_order", lib.sage_row_order_workspace_bytes(L.max_s1))
-            native.check(lib.sage_row_order(P(s1_nodes), L.max_s1, P(sc["nlive"]), first, P(sc["order"]), P(wso), wso.numel(), st), "row_order")
-            ws1 = scratch("ws_dw1", lib.sage_linear_act_backward_workspace_bytes(L.max_s1, d0p, int(self.concat), h1p))
-            native.check(lib.sage_linear_act_backward_ws(P(self.table) if self.concat else None, self.table_ld, P(s1_nodes) if self.concat else None,
-                                                         P(agg1), agg1.stride(0), d0p, P(w1p), w1p.stride(0), h1p, self.act1, P(h1), h1p,
-                                                         P(sc["grad_h1"]), h1p, L.max_s1, P(sc["nlive"]), P(g_w1p), g_w1p.stride(0), None, 0,
-                                                         P(sc["order"]), P(ws1), ws1.numel(), st),
-                         "linear_act_backward (layer 1)")
+            ws1 = scratch("ws_dw1", lib.sage_two_hop_grad_w1_workspace_bytes(b, k2, d0p, int(self.concat), h1p))
+            native.check(lib.sage_two_hop_grad_w1(P(g_x2), g_x2.stride(0), P(row2), P(cnt2), k2, P(self_row2), b, P(h1), h1p, h1p, self.act1,
+                                                  P(agg1), agg1.stride(0), d0p, int(self.concat), P(self.table) if self.concat else None,
+                                                  self.table_ld, P(s1_nodes) if self.concat else None, P(g_w1p), g_w1p.stride(0),
+                                                  P(ws1), ws1.numel(), st), "two_hop_grad_w1")
         # padded widths (Cora 1433 -> 1436, 50 -> 52): gradients of the caller's own shapes
         if self._padded:
             g_w1 = None if g_w1p is None else torch.cat([g_w1p[:self.h1, c * d0p: c * d0p + self.d0] for c in range(mult)], 1)

@@ -27,6 +27,7 @@ SYMBOLS = [
     "sage_linear_act_backward_workspace_bytes", "sage_linear_act_backward_ws",
     "sage_gather_mean_backward_workspace_bytes", "sage_gather_mean_backward_ws",
     "sage_row_order_workspace_bytes", "sage_row_order",
+    "sage_two_hop_grad_w1_workspace_bytes", "sage_two_hop_grad_w1",
     "sage_prepared_weight_bytes", "sage_prepare_weights",
     "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_profiled", "sage_pipe_submit_many",
     "sage_pipe_join", "sage_pipe_fork", "sage_pipe_reset",
@@ -118,6 +119,8 @@ def lib():
     L.sage_linear_act_backward_workspace_bytes.argtypes = [I32, I32, I32, I32]
     L.sage_linear_act_backward_ws.argtypes = [P, I64, P, P, I64, I32, P, I64, I32, I32, P, I64, P, I64, I32, P,
                                               P, I64, P, I64, P, P, c_size_t, P]
+    L.sage_two_hop_grad_w1_workspace_bytes.argtypes = [I32, I32, I32, I32, I32]
+    L.sage_two_hop_grad_w1.argtypes = [P, I64, P, P, I32, P, I32, P, I64, I32, I32, P, I64, I32, I32, P, I64, P, P, I64, P, c_size_t, P]
     L.sage_row_order_workspace_bytes.argtypes = [I32]
     L.sage_row_order.argtypes = [P, I32, P, I32, P, P, c_size_t, P]
     L.sage_gather_mean_backward_workspace_bytes.argtypes = [I32, I32, I64]

@@ -223,6 +223,23 @@ int sage_linear_act_backward_ws(const float* self_tab, int64_t ld_self, const in
 size_t sage_row_order_workspace_bytes(int32_t n);
 int sage_row_order(const int32_t* nodes, int32_t n, const int32_t* n_dev, int32_t first_row, int32_t* order,
                    void* workspace, size_t workspace_bytes, sage_stream_t stream);
+/* Layer-1 weight gradient of the TWO-LAYER stack (model.py:219-222 differentiated, model.py:249), summed over the outer samples
+ * instead of over the layer-1 rows: grad_w1 [h1, d0 or 2*d0] += sum over the seeds r, in order, of
+ *   (concat)  act1'(h1[r]) . grad_x2[r, 0:h1]  (x)  [table[s1_nodes[r]] | agg1[r]]                    (the seed's own layer-1 row)
+ *   for j < cnt2[r] (and the self-loop row):  act1'(h1[t]) . grad_x2[r, off:off+h1] / c_r  (x)  [table[s1_nodes[t]] |] agg1[t],  t = row2[r, j]
+ * (off = h1 for the concat encoder, else 0; c_r as in the forward).  Mathematically the chain mean-backward -> relu' -> dZ^T.X; in
+ * this form no grad_h1 is scattered and the terms come in (seed, slot) order, which does not depend on the frontier's arbitrary row
+ * order: bitwise reproducible without an inverted index or a canonical row order (csrc/sage_backward.hip).  grad_x2 is what
+ * sage_linear_act_backward(_ws) returned for layer 2; row2 / cnt2 / self_row2 / h1 / agg1 / s1_nodes are the forward's
+ * intermediates (sage_ws_layout_t).  Widths and leading dimensions multiples of 4, arrays 16-byte aligned. */
+size_t sage_two_hop_grad_w1_workspace_bytes(int32_t batch, int32_t k2, int32_t d0, int32_t concat, int32_t h1);
+int sage_two_hop_grad_w1(const float* grad_x2, int64_t ldgx,
+                         const int32_t* row2, const int32_t* cnt2, int32_t k2, const int32_t* self_row2, int32_t batch,
+                         const float* h1, int64_t ldh, int32_t h1_dim, int32_t act1,
+                         const float* agg1, int64_t lda, int32_t d0,
+                         int32_t concat, const float* table, int64_t table_ld, const int32_t* s1_nodes,
+                         float* grad_w1, int64_t ldgw,
+                         void* workspace, size_t workspace_bytes, sage_stream_t stream);
 size_t sage_gather_mean_backward_workspace_bytes(int32_t n, int32_t k, int64_t table_rows);
 int sage_gather_mean_backward_ws(const float* grad_agg, int64_t ldg, int32_t dim,
                                  const int32_t* nbr, const int32_t* cnt, int32_t k,
