@@ -231,6 +231,73 @@ __global__ __launch_bounds__(512) void bwd_dw_direct_kernel(const DwArgs a) {
     }
 }
 
+// ---- grad_x = dZ . W, operands straight from HBM (round 3) ------------------------------------------------------------------------
+// grad_x[m][n] = sum_h dZ(m, h) W[h][n]: M = the layer's rows, reduction over the layer's (small) output width.  A-operand lanes
+// (i = l & 31, hh = l >> 5) load 16 bytes of THEIR row of grad_out / out -- dZ(m0 + i, h0 + 4 hh + e), e = 0..3 -- and the four MFMAs
+// of a step take the reduction pairs {h0 + e, h0 + 4 + e}; the B operand W[h0 + 4 hh + e][n0 + j] is a coalesced row piece for any
+// pairing.  A wave owns 32 rows x 128 columns (four accumulators), a 256-thread block 128 rows.  No LDS, no barrier; every output
+// element is one fixed-order sum, so the result is reproducible.  The generic tile kernel took 35 us for the [4096, 128] x [128, 128]
+// product of config 3's layer 2; this form is bound by its 2 + 2 + 2 MB of traffic.
+struct DxArgs {
+    const float* gout; int64_t ldg; const float* out; int64_t ldo; int act;
+    const float* W; int64_t ldw; int H, K;             // W [H, K]: H = out_dim (reduction), K = ds + dim (grad_x's width)
+    int n_rows; const int32_t* rows_dev;
+    float* gx; int64_t ldgx;
+};
+
+__global__ __launch_bounds__(256) void bwd_dx_direct_kernel(const DxArgs a) {
+    int nrows = a.n_rows;
+    if (a.rows_dev) nrows = min(*a.rows_dev, nrows);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 128;
+    if (m0 >= nrows) return;
+    const int i = lane & 31, hh = lane >> 5;
+    const int row = min(m0 + i, nrows - 1);
+    const bool rok = m0 + i < nrows;
+    const float* gp = a.gout + (int64_t)row * a.ldg;
+    const float* yp = a.out + (int64_t)row * a.ldo;
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    for (int h0 = 0; h0 < a.H; h0 += 8) {                              // H % 4 == 0 (host-checked)
+        const int hc = h0 + 4 * hh;
+        const bool hok = hc < a.H;
+        const int hcl = min(hc, a.H - 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gp + hcl);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(yp + hcl);
+        float wv[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int n = n0 + 32 * f + i;
+                wv[e][f] = (hok && n < a.K) ? a.W[(int64_t)(hcl + e) * a.ldw + n] : 0.f;
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = g[e];
+            if (a.act == SAGE_ACT_RELU) v = y[e] > 0.f ? v : 0.f;
+            else if (a.act == SAGE_ACT_SIGMOID) v = v * y[e] * (1.f - y[e]);
+            const float dz = (rok && hok) ? v : 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, wv[e][f], acc[f], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int n = n0 + 32 * f + i;
+        if (n < a.K) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                if (m < nrows) a.gx[(int64_t)m * a.ldgx + n] = acc[f][reg];
+            }
+        }
+    }
+}
+
 // grad_W[m][n] += partial[0][m][n] + partial[1][m][n] + ... in split order (one thread per element: coalesced along n)
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, int nsplit, int M, int K, int64_t ldp,
                                                        float* __restrict__ gw, int64_t ldgw) {
@@ -509,9 +576,16 @@ int linear_act_backward_impl(const float* self_tab, int64_t ld_self, const int32
     const Dz dzo{out, ldo, grad_out, ldg, act, row_order};          // grad_W only: rows in the caller's canonical order
     const Xcat xo{self_tab, ld_self, self_index, agg, ld_agg, ds, row_order};
     if (grad_x) {
-        dim3 grid(sage_cdiv(n, BM), sage_cdiv(K, BN), 1);
-        hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1, n_dev, (int64_t)0);
-        SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_x>");
+        // 16-byte pieces of grad_out / out rows: out_dim % 4 == 0, leading dimensions % 4 == 0, 16-byte aligned bases
+        if (out_dim % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && sage_aligned(grad_out, 16) && sage_aligned(out, 16)) {
+            const DxArgs a{grad_out, ldg, out, ldo, act, weight, ldw, out_dim, K, n, n_dev, grad_x, ldgx};
+            hipLaunchKernelGGL(bwd_dx_direct_kernel, dim3(sage_cdiv(n, 128), sage_cdiv(K, 128)), dim3(256), 0, st, a);
+            SAGE_CHECK_LAUNCH("bwd_dx_direct_kernel");
+        } else {
+            dim3 grid(sage_cdiv(n, BM), sage_cdiv(K, BN), 1);
+            hipLaunchKernelGGL(bwd_gemm_kernel<0>, grid, dim3(256), 0, st, dz, x, weight, ldw, n, K, out_dim, grad_x, ldgx, 1, n_dev, (int64_t)0);
+            SAGE_CHECK_LAUNCH("bwd_gemm_kernel<grad_x>");
+        }
     }
     if (!grad_weight) return SAGE_OK;
     if (!reproducible) {
