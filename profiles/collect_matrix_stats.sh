@@ -16,28 +16,5 @@ run c3_concat --config 3 --mode concat
 run c4_rmat23 --config 4
 run c5_gcn --config 5
 run c5_concat --config 5 --mode concat
-python3 - "$O" "$TAG" "$R/profiles" <<'PY'
-import csv, glob, os, sys
-src, tag, here = sys.argv[1:4]
-OURS = ("sample_", "gather_mean", "dense_bf16x3", "dense_layer", "layer_tile16", "layer_fused", "linear_act", "prepare_weights")
-for d in sorted(os.listdir(src)):
-    p = os.path.join(src, d)
-    if not os.path.isdir(p):
-        continue
-    files = sorted(glob.glob(os.path.join(p, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
-    if not files:
-        continue
-    rows = list(csv.DictReader(open(files[-1])))
-    rows.sort(key=lambda r: (not any(k in r["Name"] for k in OURS), -float(r["TotalDurationNs"])))
-    for r in rows:
-        if len(r["Name"]) > 160:
-            r["Name"] = r["Name"][:157] + "..."
-    name = d[:-6] + "_one_batch_in_flight" if d.endswith("_alone") else d
-    with open(os.path.join(here, f"{tag}_kernel_stats_{name}.csv"), "w", newline="") as fh:
-        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        w.writerows(rows[:24])
-    ours = [r for r in rows if any(k in r["Name"] for k in OURS)][:6]
-    print(name, [(r["Name"][:40], round(float(r["AverageNs"]) / 1e3, 1)) for r in ours])
-PY
+python3 "$R/profiles/reduce_matrix_stats.py" "$O" "$TAG"     # (run it again in the build container: only gpurun_out/ travels back)
 find "$O" -name "*_kernel_trace.csv" -size +8M -delete
