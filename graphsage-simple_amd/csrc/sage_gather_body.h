@@ -6,7 +6,7 @@ namespace sage_gather_detail {
 
 // ---- column-sliced gather (wide rows, large layers) ------------------------------------------------------
 // Per-XCD L2s are private: with one wave per destination ROW every XCD ends up caching its own copy of the
-// hub rows, the L2 hit rate is ~20 % and 85 % of the gathered bytes come from beyond L2.
+// hub rows, the L2 hit rate is ~20 % and 85 % of the gathered bytes come from beyond L2 (DESIGN_HISTORY.md section 3).
 // Here a block owns one SLICE of SL*4 columns (SL lanes x 16 B) of every row it touches, and consecutive
 // blocks -- which the dispatcher deals round-robin over the 8 XCDs -- own different slices.  An XCD then only
 // ever caches its slice of the hot rows (4x more rows per L2 at 256-B slices), which is what lifts the hit rate.
