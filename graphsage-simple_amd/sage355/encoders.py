@@ -202,22 +202,21 @@ class Encoder(nn.Module):
         (an in-place optimizer step is then seen as it is), else a persistent device buffer refreshed from the host Parameter
         (strict drop-in mode, cuda=False: model.py keeps the model on the host).  -> (tensor, refreshed)"""
         w = self.weight
-        if w.is_cuda:
-            hit = self._dev_cache.get(tag)
-            if hit is None or hit[0] != w.data_ptr():
-                hit = (w.data_ptr(), w.detach())          # shares storage AND version counter with the Parameter
-                self._dev_cache[tag] = hit
-            return hit[1], False
-        key = (w.data_ptr(), w._version, tuple(w.shape))
         hit = self._dev_cache.get(tag)
-        if hit is None or hit[1].shape != w.shape:
-            hit = [None, torch.empty(w.shape, dtype=torch.float32, device="cuda")]
+        if w.is_cuda:
+            if hit is None or hit[0] != "device" or hit[1] != w.data_ptr():
+                hit = ["device", w.data_ptr(), w.detach()]          # shares storage AND version counter with the Parameter
+                self._dev_cache[tag] = hit
+            return hit[2], False
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if hit is None or hit[0] != "host" or hit[2].shape != w.shape:
+            hit = ["host", None, torch.empty(w.shape, dtype=torch.float32, device="cuda")]
             self._dev_cache[tag] = hit
-        refreshed = hit[0] != key or torch.is_grad_enabled()   # while training, never trust the key: `.data` writes do not move it
+        refreshed = hit[1] != key or torch.is_grad_enabled()   # while training, never trust the key: `.data` writes do not move it
         if refreshed:
-            hit[1].copy_(w.detach(), non_blocking=True)
-            hit[0] = key
-        return hit[1], refreshed
+            hit[2].copy_(w.detach(), non_blocking=True)
+            hit[1] = key
+        return hit[2], refreshed
 
     def _forward_two_hop(self, nodes, training=False):
         """Both layers as one C call (sage_forward2).  Under grad mode the same call is one autograd node (autograd._TwoHop)
