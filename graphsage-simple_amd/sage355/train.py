@@ -132,11 +132,15 @@ class EngineTrainer:
     the loss as a handful of torch ops on the same stream, the backward through the engine's own intermediates (nbr / cnt / row2 / h1
     stay in its workspace) with the C-ABI backward kernels, and in-place SGD updates.  No host synchronisation inside a step: the
     frontier size never leaves the device (every kernel takes its row count from the workspace).  run_training above is the
-    module-level path (the reference's class surface, Python set sampling when asked to be strict); this is the throughput path:
-    ~0.5 ms per 256-seed step on stand-in Cora against 10-12 ms there and 140-180 ms for the reference on a CPU.
+    module-level path (the reference's class surface: since round 3 it runs the same engine forward and backward as ONE autograd
+    node, ~1.2 ms per 256-seed step with the host-side classifier of model.py); this is the throughput path: 0.42 ms per 256-seed
+    step on stand-in Cora (0.24 ms as a captured hipGraph), 0.31 ms per 4096-seed step at config-3 size, against 140-180 ms for
+    the reference on a CPU.
 
     table is frozen (model.py:214-215), so layer 1 needs no input gradient.  Gradients follow torch autograd of the reference's
-    expression: d relu, d sigmoid, d mean = 1/|set| per member (sage_linear_act_backward, sage_gather_mean_backward)."""
+    expression: d relu, d sigmoid, d mean = 1/|set| per member -- TwoHopEngine.backward_weights: sage_linear_act_backward_ws for
+    layer 2, sage_two_hop_grad_w1 (the layer-1 weight gradient summed over the outer samples) for layer 1; no float atomics, two
+    runs of one schedule give the same bits."""
 
     def __init__(self, rowptr, col, table, num_classes, hidden1=50, hidden2=128, num_sample1=10, num_sample2=10, gcn=True, lr=0.7,
                  max_batch=256, agg_self_loop=False, relabel=None):
