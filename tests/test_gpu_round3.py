@@ -450,3 +450,55 @@ def test_captured_step_refuses_data_parallel_instead_of_skipping_the_all_reduce(
     ring = torch.zeros(2, 64, dtype=torch.int32, device=DEV)
     with pytest.raises(native.SageError, match="single-process"):
         tr.capture_step(ring, [1, 2], torch.zeros(graph.num_nodes, dtype=torch.int64, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------ self-loop (GCN-variant) aggregator through the backward
+@pytest.mark.parametrize("gcn", [True, False])
+def test_engine_gradients_with_the_self_loop_aggregator_match_fp64_autograd(gcn):
+    """aggregators.py:50-51 (intended semantics; parity-unpinned: the reference line raises TypeError): the node joins its own
+    neighbour set unless it was sampled anyway.  The edge-form layer-1 weight gradient carries that as an extra slot per seed;
+    checked against fp64 autograd of the set-union means on the sets the engine sampled."""
+    from sage355.train import EngineTrainer
+    graph = rmat_graph(13, 150_000, seed=4, accel=None)
+    d0, h1 = 64, 32
+    table = torch.randn(graph.num_nodes, d0, generator=torch.Generator().manual_seed(1)).to(DEV)
+    rowptr, col = graph.to(DEV)
+    torch.manual_seed(3)
+    tr = EngineTrainer(rowptr, col, table, 5, hidden1=h1, hidden2=48, num_sample1=7, num_sample2=9, gcn=gcn, max_batch=300, agg_self_loop=True)
+    seeds = np.random.default_rng(2).choice(np.nonzero(graph.degrees() > 0)[0], 300, replace=False)
+    labels = torch.from_numpy(np.random.default_rng(3).integers(0, 5, 300)).to(DEV)
+    loss, grads = tr.grads(torch.from_numpy(seeds.astype(np.int32)).to(DEV), labels, key=11)
+    e = tr.engine
+    it = e.intermediates()
+    first = it["first_frontier_row"]
+    s1 = it["s1_nodes"].cpu().long()
+    nbr1, cnt1 = it["nbr1"].cpu().long(), it["cnt1"].cpu().long()
+    row2, cnt2 = it["row2"].cpu().long(), it["cnt2"].cpu().long()
+    tab = e.table[:, :e.d0].cpu().double()
+    w1 = tr.w1.detach().cpu().double().requires_grad_(True)
+    w2 = tr.w2.detach().cpu().double().requires_grad_(True)
+    wc = tr.w_cls.detach().cpu().double().requires_grad_(True)
+
+    def union_mean(src, idx, cnt, self_idx):
+        rows = []
+        for r in range(idx.shape[0]):
+            members = [int(x) for x in idx[r, :int(cnt[r])]]
+            if int(self_idx[r]) not in members:
+                members.append(int(self_idx[r]))
+            rows.append(src[torch.tensor(members)].mean(0))
+        return torch.stack(rows)
+
+    agg1 = union_mean(tab, nbr1, cnt1, s1)                                       # layer 1: the node's own raw row joins
+    x1 = torch.cat([tab[s1], agg1], 1) if not gcn else agg1
+    hid = torch.relu(x1 @ w1.t())
+    pos = {int(v): i for i, v in enumerate(s1.tolist()) if i >= first}            # frontier row of every node id
+    self2 = torch.tensor([pos[int(s)] for s in seeds])
+    agg2 = union_mean(hid, row2, cnt2, self2)                                    # layer 2: the seed's frontier row joins
+    x2 = torch.cat([hid[:len(seeds)], agg2], 1) if not gcn else agg2
+    out = torch.relu(x2 @ w2.t())
+    ref_loss = torch.nn.functional.cross_entropy(out @ wc.t(), labels.cpu())
+    ref = torch.autograd.grad(ref_loss, (w1, w2, wc))
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * max(1.0, abs(ref_loss.item()))
+    for name, g, r in zip(("w1", "w2", "w_cls"), grads, ref):
+        err = (g.cpu().double() - r).abs().max().item() / r.abs().max().item()
+        assert err <= 2e-5, f"grad {name}: max |g - ref| / max|ref| = {err:.2e}"
