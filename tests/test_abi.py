@@ -59,6 +59,17 @@ def test_host_argument_validation_rejects_bad_calls_before_any_launch():
     assert L.sage_forward2_layout(m, 16, lay) == 0
     assert lay.max_s1 == 16 * 5 + 16 and lay.hash_capacity >= 2 * 16 * 6 and lay.total_bytes > 0
     assert lay.hash_capacity & (lay.hash_capacity - 1) == 0
+    # ABI 3 (round 3): the reproducible backward entry points validate on the host too, and their size queries are host arithmetic
+    assert L.sage_linear_act_backward_ws(None, 0, None, None, 4, 4, None, 4, 4, 0, None, 4, None, 4, 8, None, None, 4, None, 0, None, None, 0, None) == -1
+    assert L.sage_two_hop_grad_w1(None, 4, None, None, 5, None, 8, None, 4, 4, 0, None, 4, 4, 0, None, 4, None, None, 4, None, 0, None) == -1
+    assert b"NULL" in L.sage_last_error()
+    assert L.sage_gather_mean_backward_ws(None, 4, 4, None, None, 3, 8, None, None, None, None, 10, None, 4, None, 0, None) == -1
+    assert L.sage_row_order(None, 8, None, 0, None, None, 0, None) == -1
+    assert L.sage_pipe_reset(None) == -1
+    need = L.sage_linear_act_backward_workspace_bytes(23_000, 256, 0, 128)
+    assert need >= 128 * 256 * 4 and need % 4 == 0                      # at least one partial tile
+    assert L.sage_two_hop_grad_w1_workspace_bytes(4096, 25, 256, 0, 128) >= 128 * 256 * 4
+    assert L.sage_two_hop_grad_w1_workspace_bytes(4096, 25, 256, 1, 128) >= 2 * L.sage_two_hop_grad_w1_workspace_bytes(4096, 25, 256, 0, 128) - 64
 
 
 def test_module_surface_matches_reference_signatures():
