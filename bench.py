@@ -77,7 +77,9 @@ def parse():
                          "first 250 forwards of a process run 20 %% slower than the next 250); 0 = none.  Declared in config.preheat")
     ap.add_argument("--no-variant", action="store_true",
                     help="skip the second timed run with the engine in the caller's node order (reported as config.variants)")
-    ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "4")), help="pipe: batches in flight (workspaces)")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "8")),
+                    help="pipe: batches in flight (workspaces).  8 since round 3: 64.7 us per forward against 65.2 at depth 4 over 200 steps, 70.3 "
+                         "against 71.5 over 20 steps (means of four interleaved runs, experiments/r03/call18.sh)")
     ap.add_argument("--roles", default=os.environ.get("SAGE_ROLES", "SGDL"), help="pipe: roles S,G,D,L -> streams, e.g. SGDL, SGDD")
     ap.add_argument("--batches-per-replay", type=int, default=0,
                     help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "
@@ -338,6 +340,9 @@ def main():
         if pipe is not None:
             # one host call per batch (11 enqueues each): measured 2-3 us per forward FASTER than handing all K batches to the
             # C loop at once (sage_pipe_submit_many), whose only difference is that the host runs further ahead of the GPU
+            if os.environ.get("SAGE_SUBMIT_MANY") == "1":      # A/B knob: the whole region handed to the C loop at once
+                pipe.submit_many(seeds_dev[step_range.start:step_range.stop], sampler_seed[step_range.start:step_range.stop], pipe_out)
+                return
             for i in step_range:
                 pipe.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
             return
