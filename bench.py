@@ -77,9 +77,9 @@ def parse():
                          "first 250 forwards of a process run 20 %% slower than the next 250); 0 = none.  Declared in config.preheat")
     ap.add_argument("--no-variant", action="store_true",
                     help="skip the second timed run with the engine in the caller's node order (reported as config.variants)")
-    ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "8")),
-                    help="pipe: batches in flight (workspaces).  8 since round 3: 64.7 us per forward against 65.2 at depth 4 over 200 steps, 70.3 "
-                         "against 71.5 over 20 steps (means of four interleaved runs, experiments/r03/call18.sh)")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "4")),
+                    help="pipe: batches in flight (workspaces).  Depth 4 ... 8 are indistinguishable (20-step form, eight interleaved runs on "
+                         "one box: 71.2 vs 71.5 us; experiments/r03/call19.sh); under rocprofv3's tracer depth 8 is host-bound (89 vs 70 us)")
     ap.add_argument("--roles", default=os.environ.get("SAGE_ROLES", "SGDL"), help="pipe: roles S,G,D,L -> streams, e.g. SGDL, SGDD")
     ap.add_argument("--batches-per-replay", type=int, default=0,
                     help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "

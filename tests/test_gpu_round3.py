@@ -1,4 +1,4 @@
-"""Round-3 GPU tests.  The execution path bench.py TIMES -- RolePipeline, depth 8, roles SGDL, engine-internal degree layout --
+"""Round-3 GPU tests.  The execution path bench.py TIMES -- RolePipeline, depth 4, roles SGDL, engine-internal degree layout --
 at BASELINE configs[2]'s full size, checked against the oracle WITHOUT the GPU's intermediates: the sampled sets are recomputed
 by the C restatement of the sampler from (key, node id) alone, the frontier is their union, the values come from the fp64
 restatement of aggregators.py:54-74 / encoders.py:49-62 on those sets."""
@@ -32,10 +32,10 @@ def oracle_two_hop(graph, table, w1, w2, seeds, k1, k2, key, concat=False):
     return ref_sparse.two_hop_forward(table, w1, w2, seeds, nbr2, cnt2, s1, nbr1, cnt1, gcn=not concat, **kw), len(s1), int(cnt1.sum())
 
 
-@pytest.mark.parametrize("relabel,depth", [("degree", 8), (None, 4)])
+@pytest.mark.parametrize("relabel,depth", [("degree", 4), (None, 8)])
 def test_role_pipeline_at_config3_size_against_the_oracle(relabel, depth):
-    """configs[2]: R-MAT 2^20 / 16 M edges, D0 = 256, H = 128/128, fanout 15/25, B = 4096; SGDL, depth 8 with the degree layout
-    (what bench.py times) and depth 4 in the caller's order; 2 * depth + 1 batches, so that every workspace is reused at least once.  Every batch's output: (a) bit-identical to the
+    """configs[2]: R-MAT 2^20 / 16 M edges, D0 = 256, H = 128/128, fanout 15/25, B = 4096; SGDL, depth 4 with the degree layout
+    (what bench.py times) and depth 8 in the caller's order; 2 * depth + 1 batches, so that every workspace is reused at least once.  Every batch's output: (a) bit-identical to the
     single-stream forward of the same (seeds, key); (b) within 1e-5 of the row maximum of the oracle computed from the graph,
     the seeds and the key only."""
     graph = rmat_graph(20, 16_000_000, seed=0, cache_dir=CACHE)
