@@ -34,6 +34,7 @@ const sage_tunables_t& sage_tunables() {
         x.gather_rows_in_flight = env_int("SAGE_G_ROWS", 1, 1, 4);
         x.gather_trip = env_int("SAGE_G_TRIP", 16, 8, 16) >= 16 ? 16 : 8;
         x.gather_variant = env_int("SAGE_G_VARIANT", 1, 0, 2);
+        x.gather_variant_sliced = env_int("SAGE_G_VARIANT_SM", getenv("SAGE_G_VARIANT") ? x.gather_variant : 2, 0, 2);
         x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU, 32, 512);
         x.bwd_blocks = env_int("SAGE_BWD_BLOCKS", 512, 16, 4096);
         x.bwd_direct_blocks = env_int("SAGE_BWD_DIRECT_BLOCKS", 256, 16, 1024);

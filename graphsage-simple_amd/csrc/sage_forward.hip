@@ -183,8 +183,12 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     if (stages & SAGE_STAGE_GATHER1) {
     SAGE_EV(4);
     if (split1) {
-        if (int rc = sage_launch_gather_mean(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
-                                             self_loop ? s1_nodes : nullptr, nan1, agg1, m->d0, first_row, st))
+        // optional slice-major copy of the table ([d0 / 64][num_nodes][64]): every XCD pair reads ONE contiguous array
+        const int sw = m->table_slice_floats ? m->table_slice_floats : 64;
+        const bool sm = m->table_sliced != nullptr && (sw == 32 || sw == 64 || sw == 128) && m->d0 % sw == 0 && sage_aligned(m->table_sliced, 16);
+        if (int rc = sage_launch_gather_mean(sm ? m->table_sliced : m->table, m->num_nodes, sm ? sw : m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1,
+                                             s1_count, nullptr, self_loop ? s1_nodes : nullptr, nan1, agg1, m->d0, first_row, st,
+                                             sm ? m->num_nodes * (int64_t)sw : 0))
             return rc;
     }
     SAGE_EV(5);

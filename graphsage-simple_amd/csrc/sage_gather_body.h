@@ -19,7 +19,7 @@ __device__ __forceinline__ void gather_sliced_block(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0) {
     using V = __attribute__((ext_vector_type(4))) float;
     constexpr int NPI = kWave / SL;             // neighbours per wave-instruction
     // wave-instructions in flight: 8 neighbours per trip.  Deeper (4 x 4 neighbours) is no faster alone -- 32 waves per
@@ -41,6 +41,8 @@ __device__ __forceinline__ void gather_sliced_block(
     const bool ok = c0 < dim;                   // dim % 4 == 0 (host-checked)
     const bool nan_rule = any_nonempty ? (*any_nonempty != 0) : false;
     const int last_row = table_rows - 1;
+    // slice-major table (slice_stride != 0): slice s of every row is one contiguous [rows, SL * 4] array at table + s * slice_stride
+    const float* __restrict__ tcol = table + (slice_stride ? (int64_t)slice * slice_stride + gl * 4 : (int64_t)c0);
     for (int r = wave; r < nn; r += nwaves) {
         const int c = min(__builtin_amdgcn_readfirstlane(cnt[r]), kWave);   // k <= 64 (host-checked)
         int s = -1;
@@ -61,13 +63,13 @@ __device__ __forceinline__ void gather_sliced_block(
             for (int u = 0; u < U; ++u) {
                 const int j = j0 + u * NPI + grp;
                 const int id = __shfl(myid, min(j, c - 1), kWave);
-                if (ok && j < c) t[u] = *reinterpret_cast<const V*>(table + (int64_t)id * ld + c0);
+                if (ok && j < c) t[u] = *reinterpret_cast<const V*>(tcol + (int64_t)id * ld);
                 else t[u] = V{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc += t[u];
         }
-        if (extra && ok && grp == 0) acc += *reinterpret_cast<const V*>(table + (int64_t)min(s, last_row) * ld + c0);
+        if (extra && ok && grp == 0) acc += *reinterpret_cast<const V*>(tcol + (int64_t)min(s, last_row) * ld);
 #pragma unroll
         for (int m = SL; m < kWave; m <<= 1) {
             acc[0] += __shfl_xor(acc[0], m, kWave);
@@ -102,7 +104,7 @@ __device__ __forceinline__ void gather_sliced_block_pipelined(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0) {
     // R rows of the wave are in flight together (R x U wave-instructions): narrow slices (SL = 8: 128 B, one slice per
     // XCD, no hub row cached twice on the chip) put only 2 KiB of a row into one trip, too little to cover the fabric's
     // latency with the waves a shared CU can spare.
@@ -119,7 +121,7 @@ __device__ __forceinline__ void gather_sliced_block_pipelined(
     const bool ok = c0 < dim;                   // dim % 4 == 0 (host-checked)
     const bool nan_rule = any_nonempty ? (*any_nonempty != 0) : false;
     const int last_row = table_rows - 1;
-    const float* __restrict__ tcol = table + c0;
+    const float* __restrict__ tcol = table + (slice_stride ? (int64_t)slice * slice_stride + gl * 4 : (int64_t)c0);   // slice-major: see above
 
     int r0 = wave;                              // the group's rows: r0 + i * nwaves, i < R
     int c_cur[R], id_cur[R], s_cur[R];
@@ -228,7 +230,7 @@ __device__ __forceinline__ void gather_sliced_block_rows(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0) {
     using V = __attribute__((ext_vector_type(4))) float;
     constexpr int NG = kWave / SL;              // destination rows per wave-instruction
     int nn = n;
@@ -242,7 +244,7 @@ __device__ __forceinline__ void gather_sliced_block_rows(
     const bool ok = slice * SL * 4 + gl * 4 < dim;           // 16 bytes and store nothing); dim % 4 == 0 (host-checked)
     const bool nan_rule = any_nonempty ? (*any_nonempty != 0) : false;
     const int last_row = table_rows - 1;
-    const float* __restrict__ tcol = table + c0;
+    const float* __restrict__ tcol = table + (slice_stride ? (int64_t)slice * slice_stride + min(gl * 4, SL * 4 - 4) : (int64_t)c0);
     const int nblocks_rows = (nn + NG - 1) / NG;
     for (int rb = wave; rb < nblocks_rows; rb += nwaves) {
         const int r = rb * NG + grp;

@@ -40,7 +40,7 @@ int sage_launch_sample_fused(const sage_model_t* m, const int32_t* seeds, int32_
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
-                            hipStream_t st);
+                            hipStream_t st, int64_t slice_stride = 0);
 bool sage_layer_dense_supported(int32_t dim, int32_t out_dim);
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k);
 
@@ -79,6 +79,7 @@ struct sage_tunables_t {
     int gather_rows_in_flight;    // SAGE_G_ROWS          pipelined gather: rows of a wave in flight together (1 / 2 / 4), default 1
     int gather_trip;              // SAGE_G_TRIP          rows form: neighbours of a row requested per trip (8 / 16), default 16
     int gather_variant;           // SAGE_G_VARIANT       0 = three-trip rows, 1 = rows software-pipelined (default), 2 = one row per lane group
+    int gather_variant_sliced;    // SAGE_G_VARIANT_SM    the variant used with a slice-major table (sage_model_t.table_sliced): 2 (default) / 1 / 0
     int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 256
     int bwd_blocks;               // SAGE_BWD_BLOCKS      weight-gradient GEMM: blocks over (tiles x K splits), default 2 per CU (every split adds its tile with fp32 atomics)
     int bwd_direct_blocks;        // SAGE_BWD_DIRECT_BLOCKS  reproducible weight gradient: row ranges = 512-thread blocks = partial tiles (16..1024), default 256

@@ -15,7 +15,7 @@ from .ops import ACT_RELU, _chk, _need_gpu, _row_major, as_ids
 class TwoHopEngine:
     def __init__(self, rowptr, col, table, w1, w2, k1, k2, concat=False, agg_self_loop=False, act1=ACT_RELU,
                  act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None, relabel=None,
-                 prepare_weights=True):
+                 prepare_weights=True, slice_major="auto", _shared_sliced=None):
         """rowptr/col: CSR of enc1.adj_lists (inner hop); rowptr_outer/col_outer: CSR of
         enc2.adj_lists when it differs (injected pre-sampled sets), default the same.
         w1 [h1, d0 | 2*d0], w2 [h2, h1 | 2*h1]: the Encoders' `weight` Parameters
@@ -23,7 +23,7 @@ class TwoHopEngine:
         _need_gpu()
         self._ctor = dict(rowptr=rowptr, col=col, table=table, w1=w1, w2=w2, k1=k1, k2=k2, concat=concat, agg_self_loop=agg_self_loop,
                           act1=act1, act2=act2, nan_empty=nan_empty, fused=fused, max_batch=max_batch, rowptr_outer=rowptr_outer,
-                          col_outer=col_outer, relabel=relabel, prepare_weights=prepare_weights)
+                          col_outer=col_outer, relabel=relabel, prepare_weights=prepare_weights, slice_major=slice_major)
         self.rowptr1 = _chk(rowptr, torch.int64, "rowptr", 1)
         self.col1 = _chk(col, torch.int32, "col", 1)
         self.rowptr2 = self.rowptr1 if rowptr_outer is None else _chk(rowptr_outer, torch.int64, "rowptr_outer", 1)
@@ -60,6 +60,20 @@ class TwoHopEngine:
             padded = torch.zeros((self.table.shape[0], self.d0p), dtype=torch.float32, device=self.table.device)
             padded[:, :self.d0] = self.table
             self.table, self.table_ld = padded, self.d0p
+        # Slice-major second copy of the table for the column-sliced layer-1 gather: float[d0 / W][N][W] (W = 32 floats = 128-byte
+        # slices by default), so that the XCD that owns a slice reads ONE contiguous array -- consecutive hub rows' slices share DRAM
+        # pages and L2 sets -- instead of 128 bytes out of every KiB.  With it the 128-byte slices that round 2 measured SLOWER on the
+        # row-major table (fewer bytes past L2, 171 vs 214 MB, but 3.7 TB/s granules) are faster: same-box A/B at config 3, gcn encoder:
+        # row-major 65.6 us per forward, slice-major 256-B slices 62.8, 128-B slices + one destination row per lane group 60.6
+        # (gather alone 42.5 -> 37.5 us); config 4 (2^23 nodes) 96.0 -> 86.2; caller's node order 73.3 -> 61-64.  The concat encoder
+        # gets SLOWER with it (90 -> 96 us: its pacemaker is the two-pass contraction, which a more aggressive gather beside it
+        # slows down), so "auto" = gcn encoder only.  Costs a second copy of the table in HBM (1 GB of 288 at config 3); the row-major
+        # one stays for whole-row consumers (the concat encoder's own rows, the backward, read-back).
+        # slice_major: "auto" / True / False; SAGE_TABLE_SLICED=0 disables, SAGE_TABLE_SLICE_FLOATS = 32 / 64 / 128 picks W.
+        import os
+        self._table_sliced = _shared_sliced
+        self._table_sliced_version = self.table._version
+        self._want_sliced = slice_major is True or (slice_major == "auto" and not concat and os.environ.get("SAGE_TABLE_SLICED", "1") != "0")
         self._wpad_key = None
         self._w1p = self._w2p = None
         self._w1prep = self._w1prep_key = None
@@ -117,7 +131,7 @@ class TwoHopEngine:
         e = TwoHopEngine(self.rowptr1, self.col1, self.table, self.w1, self.w2, self.k1, self.k2, concat=self.concat,
                          agg_self_loop=self.agg_self_loop, act1=self.act1, act2=self.act2, nan_empty=self.nan_empty, fused=self.fused,
                          max_batch=self.max_batch, rowptr_outer=self.rowptr2, col_outer=self.col2, relabel=None,
-                         prepare_weights=self.prepare_weights)
+                         prepare_weights=self.prepare_weights, slice_major=self._table_sliced is not None, _shared_sliced=self._table_sliced)
         e.node_order, e._new_of_old = self.node_order, self._new_of_old
         e._model_key = None
         return e
@@ -172,7 +186,26 @@ class TwoHopEngine:
             self._w1prep_key = key
         return self._w1prep
 
+    def _slice_table(self):
+        """Build (or refresh, if the table was written in place since) the slice-major copy -- only when layer 1 runs as the
+        column-sliced gather with 256-byte slices of whole 64-float pieces."""
+        import os
+        w = int(os.environ.get("SAGE_TABLE_SLICE_FLOATS", "32"))         # floats per slice: 32 (128 B, default) / 64 / 128
+        self._slice_floats = w
+        ok = (self._want_sliced and bool(self.layout.layer1_split) and w in (32, 64, 128) and self.d0p % w == 0 and self.d0p >= 2 * w
+              and self.table_ld == self.d0p and self.table.shape[0] == self.num_nodes)
+        if not ok:
+            self._table_sliced = None
+            return
+        if self._table_sliced is None or self._table_sliced_version != self.table._version:
+            n_rows = self.table.shape[0]
+            self._table_sliced = self.table.view(n_rows, self.d0p // w, w).permute(1, 0, 2).contiguous()
+            self._table_sliced_version = self.table._version
+            self._model_key = None
+
     def _model(self, queued=False):
+        if self.layout.total_bytes:          # the layout is known (after the first _reserve)
+            self._slice_table()
         w1, w2 = self._weights()
         prep = self._prepare_w1(w1.detach())
         key = (w1.data_ptr(), w2.data_ptr(), self._queue.data_ptr() if self._queue is not None else 0, prep.data_ptr() if prep is not None else 0)
@@ -189,6 +222,8 @@ class TwoHopEngine:
             int(self.max_batch))
         self._model_c.w1_prepared = prep.data_ptr() if prep is not None else None
         self._model_c.seed_map = self._new_of_old.data_ptr() if self._new_of_old is not None else None
+        self._model_c.table_sliced = self._table_sliced.data_ptr() if self._table_sliced is not None else None
+        self._model_c.table_slice_floats = getattr(self, "_slice_floats", 64)
         self._model_q = None
         if self._queue is not None:
             self._model_q = native.Model.from_buffer_copy(self._model_c)

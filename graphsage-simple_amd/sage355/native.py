@@ -50,7 +50,8 @@ class Model(Structure):
                 ("w1", c_void_p), ("h1", c_int32), ("w2", c_void_p), ("h2", c_int32),
                 ("k1", c_int32), ("k2", c_int32), ("concat", c_int32), ("agg_self_loop", c_int32),
                 ("act1", c_int32), ("act2", c_int32), ("nan_empty", c_int32), ("fused", c_int32), ("ws_batch", c_int32),
-                ("queue", c_void_p), ("queue_len", c_int32), ("queue_cursor", c_void_p), ("w1_prepared", c_void_p), ("seed_map", c_void_p)]
+                ("queue", c_void_p), ("queue_len", c_int32), ("queue_cursor", c_void_p), ("w1_prepared", c_void_p), ("seed_map", c_void_p),
+                ("table_sliced", c_void_p), ("table_slice_floats", c_int32)]
 
 
 class Batch(Structure):      # sage_batch_t, lives in device memory (16 bytes)

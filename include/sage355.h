@@ -299,6 +299,10 @@ typedef struct {
      * order of its own (sage355.engine: rows sorted by descending degree, so that the most-gathered feature rows are
      * neighbours in HBM) translates every seed with it INSIDE the outer-hop kernel; NULL = ids are used as they are. */
     const int32_t* seed_map;
+    /* optional (ABI 3): a second copy of the table in SLICE-MAJOR order, float[d0 / W][num_nodes][W], W = table_slice_floats (d0 % W == 0): the
+     * column-sliced layer-1 gather then reads one contiguous array per 256-byte slice.  NULL = gather from `table`. */
+    const float*   table_sliced;
+    int32_t        table_slice_floats;  /* floats per slice of table_sliced: 64 (256-byte slices; 0 means 64) or 32 / 128; d0 % it == 0 */
 } sage_model_t;
 
 /* Where the intermediates of one forward live inside the caller's workspace
