@@ -265,6 +265,7 @@ def main():
     relabel = "degree" if (args.engine_layout == "degree" and args.config != 2 and args.node_order != "degree") else None
     ekw = dict(concat=concat, agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel)
     base = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, **ekw)
+    base_split = base.layout.layer1_split
     nstreams = max(1, args.streams)
 
     # ---- parity gate: one batch against the fp64 oracle on the GPU's own sampled sets.  The batch is the LAST one of the timed
@@ -638,6 +639,9 @@ def main():
                        "node_order": args.node_order if args.config != 2 else "original",
                        "engine_layout": (relabel or "input") + (" (internal: rows by descending degree; seeds arrive in the generator's ids and are "
                                                                 "translated inside every timed forward)" if relabel else ""),
+                       "table_layout": (f"engine-internal: row-major [N, {d0}] + a slice-major copy [{d0 // 32}][N][32] read by the column-sliced "
+                                        "layer-1 gather (128-byte slices, one per XCD)" if (not concat and d0 % 32 == 0 and d0 >= 64 and
+                                        os.environ.get("SAGE_TABLE_SLICED", "1") != "0" and bool(base_split)) else "row-major"),
                        "contraction": "bf16x3-split MFMA (fp32-accurate: x.w from the three bf16 terms of x and of w; weight planes prepared "
                                       "once per weight update by sage_prepare_weights)",
                        "batches_per_replay": bpr if exec_mode == "replay" else 1,

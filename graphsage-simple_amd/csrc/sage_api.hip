@@ -38,7 +38,9 @@ const sage_tunables_t& sage_tunables() {
         x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU, 32, 512);
         x.bwd_blocks = env_int("SAGE_BWD_BLOCKS", 512, 16, 4096);
         x.bwd_direct_blocks = env_int("SAGE_BWD_DIRECT_BLOCKS", 256, 16, 1024);
-        const int so = env_int("SAGE_SO_THREADS", 1024, 256, 1024);
+        // 512 since round 3: once the slice-major table took the gather off the critical path the sampler stream showed up --
+        // 58.9 vs 61.0 us per forward (200 steps), 65.6 vs 67.2 (20 steps), four interleaved runs each (experiments/r03/call30.sh)
+        const int so = env_int("SAGE_SO_THREADS", 512, 256, 1024);
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);
         x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);

@@ -83,7 +83,7 @@ struct sage_tunables_t {
     int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 256
     int bwd_blocks;               // SAGE_BWD_BLOCKS      weight-gradient GEMM: blocks over (tiles x K splits), default 2 per CU (every split adds its tile with fp32 atomics)
     int bwd_direct_blocks;        // SAGE_BWD_DIRECT_BLOCKS  reproducible weight gradient: row ranges = 512-thread blocks = partial tiles (16..1024), default 256
-    int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 1024
+    int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 512 (1024 until round 3)
     int tile16_grid;              // SAGE_T16_GRID        layer-2 tile16 kernel: max blocks (64..1024), default 512
     int sample_fused;             // SAGE_SAMPLE_FUSED    1: both hops in one launch when layer 2 is a one-launch layer; 0 (default): two launches
                                   //                      (measured: 24.3 us fused vs 10.3 + 11.4: the inner hop of a block's own winners is
