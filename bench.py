@@ -80,6 +80,11 @@ def parse():
     ap.add_argument("--depth", type=int, default=int(os.environ.get("SAGE_DEPTH", "4")),
                     help="pipe: batches in flight (workspaces).  Depth 4 ... 8 are indistinguishable (20-step form, eight interleaved runs on "
                          "one box: 71.2 vs 71.5 us; experiments/r03/call19.sh); under rocprofv3's tracer depth 8 is host-bound (89 vs 70 us)")
+    ap.add_argument("--host-threads", type=int, choices=[0, 1], default=int(os.environ.get("SAGE_BENCH_THREADS", "1")),
+                    help="pipe: 1 (default) = one host enqueue thread per role stream (sage_pipe_set_threads: a submit only posts the batch, "
+                         "the four streams are fed in parallel); 0 = the submitting thread makes all thirteen HIP calls of a batch itself")
+    ap.add_argument("--window", type=int, default=int(os.environ.get("SAGE_PIPE_WINDOW", "0")),
+                    help="pipe with host threads: role S enqueues batch b only once batch b - window has left the GPU (0 = unbounded)")
     ap.add_argument("--roles", default=os.environ.get("SAGE_ROLES", "SGDL"), help="pipe: roles S,G,D,L -> streams, e.g. SGDL, SGDD")
     ap.add_argument("--batches-per-replay", type=int, default=0,
                     help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "
@@ -303,7 +308,8 @@ def main():
     engines, streams, outs = [], [], []
     pipe_graphs = None
     if exec_mode in ("pipe", "pipegraph"):
-        pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, **ekw)
+        pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles,
+                            threads=bool(args.host_threads) and exec_mode == "pipe" and len(set(args.roles)) == 4, window=args.window, **ekw)
         pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
         torch.cuda.synchronize()
         if exec_mode == "pipegraph":
@@ -330,6 +336,8 @@ def main():
                     else:
                         engines[s].capture(batches=bpr)
             torch.cuda.synchronize()
+
+    pipe_threaded = bool(pipe is not None and pipe.threads)
 
     def run(step_range):
         if pipe_graphs is not None:
@@ -361,7 +369,9 @@ def main():
                 else:
                     engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s])
 
-    def fence():
+    def fence(p=None):
+        if p is not None:
+            p.flush()                             # host enqueue threads: everything submitted is on the streams
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -379,6 +389,7 @@ def main():
         while time.perf_counter() - t_ph < args.preheat_seconds:
             if pipe is not None:
                 pipe.submit_many(ph_seeds, ph_keys, pipe_out)
+                pipe.flush()
             else:
                 for i in range(ph_n):
                     ph_eng.forward(ph_seeds[i], seed=ph_keys[i])
@@ -389,11 +400,14 @@ def main():
                 pass
     # ---- warm-up, then the timed region: exactly K steps between two barrier+synchronize fences ----
     run(range(args.warmup))
-    fence()
+    fence(pipe)
     t0 = time.perf_counter()
     run(range(args.warmup, total_steps))
-    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # how long the host needed per step (it must stay below ms_per_step)
-    fence()
+    host_submit_ms = (time.perf_counter() - t0) / args.steps * 1e3       # the submitting thread, per step
+    if pipe is not None:
+        pipe.flush()
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # until the last HIP call of the region was made (it must stay below ms_per_step)
+    fence(pipe)
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
@@ -579,20 +593,25 @@ def main():
     variants = None
     if rank == 0 and world == 1 and pipe is not None and relabel is not None and not args.no_variant:
         role_streams = pipe.distinct_streams()       # the variant runs on the SAME role streams (hence hardware queues)
+        pipe_threads = pipe.threads
         del pipe
         torch.cuda.synchronize()
         ekw_in = dict(ekw, relabel=None)
-        pipe_in = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, streams=role_streams, **ekw_in)
+        pipe_in = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, streams=role_streams,
+                               threads=pipe_threads, window=args.window, **ekw_in)
         t_ph = time.perf_counter()
         while time.perf_counter() - t_ph < min(args.preheat_seconds, 0.2):
             pipe_in.submit_many(ph_seeds, ph_keys, pipe_out) if args.preheat_seconds > 0 else None
+            pipe_in.flush()
             torch.cuda.synchronize()
         for i in range(args.warmup):
             pipe_in.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
+        pipe_in.flush()
         torch.cuda.synchronize()
         t0v = time.perf_counter()
         for i in range(args.warmup, total_steps):
             pipe_in.submit(seeds_dev[i], sampler_seed[i], pipe_out[i % pipe_out.shape[0]])
+        pipe_in.flush()
         torch.cuda.synchronize()
         el_v = time.perf_counter() - t0v
         variants = {"engine_layout_input": {"value": round(b * args.steps / el_v, 1), "ms_per_step": round(el_v / args.steps * 1e3, 5),
@@ -622,6 +641,8 @@ def main():
     if rank == 0:
         if was_pipe:
             execution = f"role pipeline {args.roles} (stages S/G/D/L on HIP streams, hipEvent hand-offs), {args.depth} batches in flight"
+            if pipe_threaded:
+                execution += ", one host enqueue thread per role stream" + (f", host run-ahead window {args.window}" if args.window else "")
             if exec_mode == "pipegraph":
                 execution += f"; the {args.steps} timed batches captured as ONE hipGraph over the role streams (one graph launch per timed region)"
         elif exec_mode == "replay":
@@ -634,7 +655,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
-                       "execution": execution, "host_enqueue_ms_per_step": round(host_enqueue_ms, 5), "fused_layers": not args.unfused,
+                       "execution": execution, "host_enqueue_ms_per_step": round(host_enqueue_ms, 5),
+                       "host_submit_ms_per_step": round(host_submit_ms, 5), "fused_layers": not args.unfused,
                        "preheat": f"{preheat_forwards} untimed forwards on throw-away batches before the {args.warmup} warm-up steps (GPU clock ramp)",
                        "node_order": args.node_order if args.config != 2 else "original",
                        "engine_layout": (relabel or "input") + (" (internal: rows by descending degree; seeds arrive in the generator's ids and are "
@@ -688,20 +710,22 @@ def scaling_variant(args, rank, world, dev, dist, fence):
     keys = [0x5A6E355 + 1000003 * rank + i for i in range(total)]
     relabel = "degree" if args.engine_layout == "degree" else None
     pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, concat=concat,
-                        agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel)
+                        agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel,
+                        threads=bool(args.host_threads) and len(set(args.roles)) == 4, window=args.window)
     out = torch.empty(max(args.depth, 4), b, h2, device=dev)
     torch.cuda.synchronize()
     t_ph = time.perf_counter()
     while time.perf_counter() - t_ph < min(args.preheat_seconds, 0.3):
         pipe.submit_many(seeds[:min(total, 8)], keys[:min(total, 8)], out)
+        pipe.flush()
         torch.cuda.synchronize()
     for i in range(args.warmup):
         pipe.submit(seeds[i], keys[i], out[i % out.shape[0]])
-    fence()
+    fence(pipe)
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         pipe.submit(seeds[i], keys[i], out[i % out.shape[0]])
-    fence()
+    fence(pipe)
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)

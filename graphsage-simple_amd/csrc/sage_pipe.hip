@@ -27,11 +27,41 @@
 // left as the tail of stream L is read back with hipStreamGetCaptureInfo_v2 right after it is enqueued, and added to S's next node
 // with hipStreamUpdateCaptureDependencies -- the very same graph captures, instantiates and replays correctly (patterns 15, 17).
 // submit_one does exactly that while the role streams are capturing; eager submission keeps the event.
+//
+// Host enqueue threads (round 3, sage_pipe_set_threads).  One batch is thirteen HIP calls (five launches, four records, four
+// waits): 40-60 us of host time on one thread, next to a 59 us period on the GPU -- the host was as good as the pacemaker, and in a
+// short timed region (20 steps) the GPU chased the host through the whole region.  With the threads on, sage_pipe_submit only POSTS a
+// descriptor (seeds, key, out, slot); role r's own thread makes role r's calls on role r's stream, so the four streams are fed in
+// parallel.  HIP's event semantics fix the order of the HOST calls across threads: hipStreamWaitEvent(ev) means "the most recent
+// hipEventRecord(ev) made before this call", so thread r may touch batch b only after thread r-1 has recorded for batch b (and S(b)
+// after L(b - depth)): one atomic counter per role (`done[r]` = batches whose calls role r has made), acquire / release.  The same
+// chain guarantees that an event is re-recorded (batch b + depth) only after its consumer's wait for batch b has been made.
+// Everything that looks at the streams from outside (join, fork, reset, update_weights, destroy) first drains the posted batches
+// (sage_pipe_flush).  Needs four distinct role streams; not available inside a stream capture.
+#include <sched.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "sage_internal.h"
+
+namespace {
+enum { kRing = 256, kDoneEvents = 32 };
+struct pipe_desc {                                      // one posted batch
+    const int32_t* seeds;
+    uint64_t key;
+    float* out;
+    int64_t ldo;
+    int slot;
+    bool fresh;
+    void* gev[2];
+};
+}  // namespace
 
 struct sage_pipe {
     sage_model_t model;
@@ -43,6 +73,21 @@ struct sage_pipe {
     hipEvent_t ev[4][SAGE_PIPE_MAX_DEPTH];              // [role][slot]: role's work on the slot's batch is enqueued
     hipEvent_t ev_fork;
     uint64_t submitted;
+    // host enqueue threads
+    int device;
+    bool threaded;
+    int window;                                         // > 0: S(b) is enqueued only once batch b - window has LEFT the GPU (host run-ahead bound)
+    std::thread th[4];
+    std::atomic<uint64_t> posted{0};                    // batches posted by the caller (threaded mode: == submitted)
+    std::atomic<uint64_t> done[4];                      // batches whose calls role r's thread has made
+    std::atomic<int> stop{0};
+    std::atomic<int> sleepers{0};
+    std::atomic<int> worker_rc{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    char worker_err[512];
+    pipe_desc ring[kRing];
+    hipEvent_t ev_done[kDoneEvents];                    // window > 0: recorded on stream L behind batch b (index b % kDoneEvents)
     // while capturing: the graph node(s) layer 2 of the slot's last batch left as the tail of stream L, and the capture they belong to
     hipGraphNode_t cap_nodes[SAGE_PIPE_MAX_DEPTH][4];
     int cap_count[SAGE_PIPE_MAX_DEPTH];
@@ -111,6 +156,13 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     p->depth = depth;
     p->ws_bytes = workspace_bytes;
     p->submitted = 0;
+    p->threaded = false;
+    p->window = 0;
+    p->device = 0;
+    p->worker_err[0] = 0;
+    (void)hipGetDevice(&p->device);
+    for (int r = 0; r < 4; ++r) p->done[r].store(0);
+    for (int i = 0; i < kDoneEvents; ++i) p->ev_done[i] = nullptr;
     for (int i = 0; i < SAGE_PIPE_MAX_DEPTH; ++i) { p->cap_count[i] = 0; p->cap_id[i] = 0; }
     for (int i = 0; i < depth; ++i) p->ws[i] = workspaces[i];
     for (int r = 0; r < 4; ++r) p->st[r] = (hipStream_t)streams[r];
@@ -133,8 +185,13 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     return SAGE_OK;
 }
 
+static void stop_threads(sage_pipe* p);
+
 extern "C" int sage_pipe_destroy(sage_pipe_t* p) {
     if (!p) return SAGE_OK;
+    stop_threads(p);
+    for (int i = 0; i < kDoneEvents; ++i)
+        if (p->ev_done[i]) (void)hipEventDestroy(p->ev_done[i]);
     for (int r = 0; r < 4; ++r)
         for (int i = 0; i < p->depth; ++i)
             if (p->ev[r][i]) (void)hipEventDestroy(p->ev[r][i]);
@@ -145,67 +202,227 @@ extern "C" int sage_pipe_destroy(sage_pipe_t* p) {
 
 extern "C" int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2, const void* w1_prepared) {
     SAGE_REQUIRE(p && w1 && w2, "pipe_update_weights: NULL argument");
+    if (int rc = sage_pipe_flush(p)) return rc;          // the role threads read p->model
     p->model.w1 = w1;
     p->model.w2 = w2;
     p->model.w1_prepared = w1_prepared;
     return SAGE_OK;
 }
 
-// One batch through the four role streams.  `fresh_slot`: no earlier submit of this pipe is outstanding on the slot (a fresh
-// pipe, or the first `depth` submits after the caller joined and synchronised everything before): the workspace-release wait
-// is skipped.
-static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot,
-                      void* const* gather_events = nullptr) {
-    const int slot = (int)(p->submitted % (uint64_t)p->depth);
+// Role r's calls for one batch, on role r's stream: wait for the producer's event, launch, record.  `fresh`: no earlier submit of
+// this pipe is outstanding on the slot (a fresh pipe, or the first `depth` submits after the caller joined and synchronised
+// everything before): the workspace-release wait is skipped.  Called for r = S, G, D, L in turn by the caller's thread
+// (submit_one), or by role r's own thread.
+static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long long cap) {
     const sage_model_t* m = &p->model;
+    const int slot = d.slot;
     void* ws = p->ws[slot];
-    // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
-    unsigned long long cap = 0;
-    if (int rc = capture_id(p->st[RS], &cap)) return rc;
-    if (!fresh_slot && p->st[RS] != p->st[RL]) {
-        if (cap != 0) {
-            // captured: the release edge as an explicit node dependency (an event wait here crashes hipStreamEndCapture, see above)
-            SAGE_REQUIRE(p->cap_id[slot] == cap && p->cap_count[slot] > 0,
-                         "pipe: inside a stream capture the first `depth` submits must find their workspaces free: join everything "
-                         "submitted before, begin the capture, and pass segment_start (sage_pipe_submit_many) / call sage_pipe_reset");
-            if (hipStreamUpdateCaptureDependencies(p->st[RS], p->cap_nodes[slot], (size_t)p->cap_count[slot], hipStreamAddCaptureDependencies) != hipSuccess) {
-                sage_set_error("pipe: hipStreamUpdateCaptureDependencies failed");
-                return SAGE_ELAUNCH;
+    switch (r) {
+    case RS:
+        // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
+        if (!d.fresh && p->st[RS] != p->st[RL]) {
+            if (cap != 0) {
+                // captured: the release edge as an explicit node dependency (an event wait here crashes hipStreamEndCapture, see above)
+                SAGE_REQUIRE(p->cap_id[slot] == cap && p->cap_count[slot] > 0,
+                             "pipe: inside a stream capture the first `depth` submits must find their workspaces free: join everything "
+                             "submitted before, begin the capture, and pass segment_start (sage_pipe_submit_many) / call sage_pipe_reset");
+                if (hipStreamUpdateCaptureDependencies(p->st[RS], p->cap_nodes[slot], (size_t)p->cap_count[slot], hipStreamAddCaptureDependencies) != hipSuccess) {
+                    sage_set_error("pipe: hipStreamUpdateCaptureDependencies failed");
+                    return SAGE_ELAUNCH;
+                }
+            } else {
+                SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset "
+                                                   "(after synchronising) before submitting eagerly again");
+                if (int rc = wait_on(p, RS, RL, slot)) return rc;
             }
-        } else {
-            SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset "
-                                               "(after synchronising) before submitting eagerly again");
-            if (int rc = wait_on(p, RS, RL, slot)) return rc;
         }
-    }
 #ifndef SAGE_PIPE_SKIP_S   // diagnostic builds only (experiments/ab_build.sh).  _G and _D may be skipped alone (stale data downstream); _S and _L
                            // only together with everything else ("events only"): the samplers fill and layer 2 wipes the frontier hash, and
                            // one without the other leaves a full table behind (an outer sampler probing it took 67 ms per batch)
-    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0,
-                                             SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
-        return rc;
+        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0,
+                                                 SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
+            return rc;
 #endif
-    if (int rc = record(p, RS, slot, p->st[RG] != p->st[RS])) return rc;
-    // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
-    if (int rc = wait_on(p, RG, RS, slot)) return rc;
-    if (gather_events && gather_events[0] && hipEventRecord((hipEvent_t)gather_events[0], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
+        return record(p, RS, slot, p->st[RG] != p->st[RS]);
+    case RG:
+        // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
+        if (int rc = wait_on(p, RG, RS, slot)) return rc;
+        if (d.gev[0] && hipEventRecord((hipEvent_t)d.gev[0], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
 #ifndef SAGE_PIPE_SKIP_G   // diagnostic builds (experiments/ab_build.sh): the pipeline without one of its stages' kernels, stale data downstream
-    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG])) return rc;
+        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG])) return rc;
 #endif
-    if (gather_events && gather_events[1] && hipEventRecord((hipEvent_t)gather_events[1], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
-    if (int rc = record(p, RG, slot, p->st[RD] != p->st[RG])) return rc;
-    // D: the contraction (or the whole fused layer 1)
-    if (int rc = wait_on(p, RD, RG, slot)) return rc;
+        if (d.gev[1] && hipEventRecord((hipEvent_t)d.gev[1], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
+        return record(p, RG, slot, p->st[RD] != p->st[RG]);
+    case RD:
+        // D: the contraction (or the whole fused layer 1)
+        if (int rc = wait_on(p, RD, RG, slot)) return rc;
 #ifndef SAGE_PIPE_SKIP_D
-    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
+        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
 #endif
-    if (int rc = record(p, RD, slot, p->st[RL] != p->st[RD])) return rc;
-    // L: layer 2; afterwards the workspace is clean again
-    if (int rc = wait_on(p, RL, RD, slot)) return rc;
+        return record(p, RD, slot, p->st[RL] != p->st[RD]);
+    default:
+        // L: layer 2; afterwards the workspace is clean again
+        if (int rc = wait_on(p, RL, RD, slot)) return rc;
 #ifndef SAGE_PIPE_SKIP_L
-    if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, seeds, p->batch, key, out, ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
+        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
 #endif
-    if (int rc = record(p, RL, slot, p->st[RS] != p->st[RL])) return rc;
+        return record(p, RL, slot, p->st[RS] != p->st[RL]);
+    }
+}
+
+// ---- host enqueue threads ------------------------------------------------------------------------------------------------
+namespace {
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// spin (pause, then yield) until pred() or the pipe stops; false = stopped
+template <class Pred>
+bool spin_until(sage_pipe* p, Pred pred) {
+    for (unsigned n = 0; !pred(); ++n) {
+        if (p->stop.load(std::memory_order_relaxed)) return false;
+        if (n < 4096) cpu_relax(); else sched_yield();
+    }
+    return true;
+}
+
+void worker_fail(sage_pipe* p, int rc) {
+    int expected = 0;
+    if (p->worker_rc.compare_exchange_strong(expected, rc)) {
+        std::lock_guard<std::mutex> g(p->mu);
+        snprintf(p->worker_err, sizeof(p->worker_err), "%s", sage_last_error());
+    }
+}
+
+void role_thread(sage_pipe* p, int r) {
+    (void)hipSetDevice(p->device);
+    uint64_t b = p->done[r].load(std::memory_order_relaxed);
+    for (;;) {
+        // a posted batch: spin for a while (a running pipeline posts every few tens of microseconds), then sleep
+        bool have = false;
+        for (unsigned n = 0; n < 200000; ++n) {
+            if (p->posted.load(std::memory_order_acquire) > b) { have = true; break; }
+            if (p->stop.load(std::memory_order_relaxed)) return;
+            cpu_relax();
+        }
+        if (!have) {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->sleepers.fetch_add(1);
+            while (p->posted.load(std::memory_order_acquire) <= b && !p->stop.load(std::memory_order_relaxed))
+                p->cv.wait_for(lk, std::chrono::milliseconds(2));
+            p->sleepers.fetch_sub(1);
+            if (p->stop.load(std::memory_order_relaxed)) return;
+        }
+        const pipe_desc& d = p->ring[b % kRing];
+        // the HOST order HIP's event semantics need: the producer's record for this batch has been made
+        if (r == RS) {
+            if (!d.fresh && !spin_until(p, [&] { return p->done[RL].load(std::memory_order_acquire) + (uint64_t)p->depth > b; })) return;
+            if (p->window > 0 && b >= (uint64_t)p->window) {
+                // bound the host's run-ahead: batch b - window has left the GPU (its marker on stream L has completed)
+                hipEvent_t e = p->ev_done[(b - (uint64_t)p->window) % kDoneEvents];
+                if (!spin_until(p, [&] { return hipEventQuery(e) != hipErrorNotReady; })) return;
+            }
+        } else if (!spin_until(p, [&] { return p->done[r - 1].load(std::memory_order_acquire) > b; })) {
+            return;
+        }
+        if (p->worker_rc.load(std::memory_order_relaxed) == 0) {      // after a failure nothing more is enqueued; the counters still advance
+            int rc = role_enqueue(p, r, d, 0);
+            if (rc == SAGE_OK && r == RL && p->window > 0 && hipEventRecord(p->ev_done[b % kDoneEvents], p->st[RL]) != hipSuccess) {
+                sage_set_error("pipe: hipEventRecord failed");
+                rc = SAGE_ELAUNCH;
+            }
+            if (rc != SAGE_OK) worker_fail(p, rc);
+        }
+        ++b;
+        p->done[r].store(b, std::memory_order_release);
+    }
+}
+
+int post(sage_pipe* p, const pipe_desc& d) {
+    // the ring holds the descriptors the role threads have not finished with
+    if (!spin_until(p, [&] { return p->submitted - p->done[RL].load(std::memory_order_acquire) < (uint64_t)kRing - 1; })) return SAGE_ELAUNCH;
+    p->ring[p->submitted % kRing] = d;
+    ++p->submitted;
+    p->posted.store(p->submitted, std::memory_order_seq_cst);
+    if (p->sleepers.load(std::memory_order_seq_cst) > 0) {
+        { std::lock_guard<std::mutex> g(p->mu); }
+        p->cv.notify_all();
+    }
+    return SAGE_OK;
+}
+}  // namespace
+
+static void stop_threads(sage_pipe* p) {
+    if (!p->threaded) return;
+    (void)sage_pipe_flush(p);
+    p->stop.store(1);
+    { std::lock_guard<std::mutex> g(p->mu); }
+    p->cv.notify_all();
+    for (int r = 0; r < 4; ++r)
+        if (p->th[r].joinable()) p->th[r].join();
+    p->stop.store(0);
+    p->threaded = false;
+}
+
+// Every posted batch has been enqueued on the role streams (NOT: has run).  Returns the first error a role thread met.
+extern "C" int sage_pipe_flush(sage_pipe_t* p) {
+    SAGE_REQUIRE(p, "pipe_flush: NULL pipe");
+    if (!p->threaded) return SAGE_OK;
+    for (unsigned n = 0; p->done[RL].load(std::memory_order_acquire) < p->submitted; ++n) {
+        if (n < 4096) cpu_relax(); else sched_yield();
+    }
+    const int rc = p->worker_rc.load();
+    if (rc != SAGE_OK) {
+        std::lock_guard<std::mutex> g(p->mu);
+        sage_set_error("pipe (role thread): %s", p->worker_err);
+    }
+    return rc;
+}
+
+// on != 0: start one host enqueue thread per role; on == 0: drain and stop them.  window > 0 bounds the host's run-ahead: role S
+// enqueues batch b only when batch b - window has left the GPU (0 = unbounded).
+extern "C" int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window) {
+    SAGE_REQUIRE(p, "pipe_set_threads: NULL pipe");
+    SAGE_REQUIRE(window >= 0 && window < kDoneEvents, "pipe_set_threads: window = %d outside [0, %d)", window, (int)kDoneEvents);
+    stop_threads(p);
+    if (!on) return SAGE_OK;
+    for (int r = 0; r < 4; ++r)
+        for (int q = 0; q < r; ++q) SAGE_REQUIRE(p->st[q] != p->st[r], "pipe_set_threads: the host enqueue threads need four distinct role streams");
+    unsigned long long cap = 0;
+    if (int rc = capture_id(p->st[RS], &cap)) return rc;
+    SAGE_REQUIRE(cap == 0, "pipe_set_threads: not inside a stream capture");
+    if (window > 0)
+        for (int i = 0; i < kDoneEvents; ++i)
+            if (!p->ev_done[i] && hipEventCreateWithFlags(&p->ev_done[i], kEventFlags) != hipSuccess) {
+                sage_set_error("pipe_set_threads: hipEventCreate failed");
+                return SAGE_ELAUNCH;
+            }
+    p->window = window;
+    p->worker_rc.store(0);
+    p->posted.store(p->submitted);
+    for (int r = 0; r < 4; ++r) p->done[r].store(p->submitted);
+    p->threaded = true;
+    for (int r = 0; r < 4; ++r) p->th[r] = std::thread(role_thread, p, r);
+    return SAGE_OK;
+}
+
+// One batch through the four role streams.
+static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot,
+                      void* const* gather_events = nullptr) {
+    pipe_desc d;
+    d.seeds = seeds; d.key = key; d.out = out; d.ldo = ldo;
+    d.slot = (int)(p->submitted % (uint64_t)p->depth);
+    d.fresh = fresh_slot;
+    d.gev[0] = gather_events ? gather_events[0] : nullptr;
+    d.gev[1] = gather_events ? gather_events[1] : nullptr;
+    const int slot = d.slot;
+    if (p->threaded) {
+        SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset first");
+        if (int rc = p->worker_rc.load()) { sage_set_error("pipe: a role thread failed earlier (sage_pipe_flush reports it)"); return rc; }
+        return post(p, d);
+    }
+    unsigned long long cap = 0;
+    if (int rc = capture_id(p->st[RS], &cap)) return rc;
+    for (int r = 0; r < 4; ++r)
+        if (int rc = role_enqueue(p, r, d, cap)) return rc;
     p->cap_id[slot] = 0;
     p->cap_count[slot] = 0;
     if (cap != 0 && p->st[RS] != p->st[RL]) {               // remember the node layer 2 left as the tail of stream L
@@ -230,7 +447,15 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
 // submitted before -- e.g. after a stream capture ended, before eager submission resumes on the same pipe.
 extern "C" int sage_pipe_reset(sage_pipe_t* p) {
     SAGE_REQUIRE(p, "pipe_reset: NULL pipe");
+    if (int rc = sage_pipe_flush(p)) return rc;
     p->submitted = 0;
+    if (p->threaded) {
+        // the role threads are idle (everything posted has been enqueued) and wait for posted > done: restart their numbering
+        const int window = p->window;
+        stop_threads(p);
+        for (int i = 0; i < SAGE_PIPE_MAX_DEPTH; ++i) { p->cap_count[i] = 0; p->cap_id[i] = 0; }
+        return sage_pipe_set_threads(p, 1, window);
+    }
     for (int i = 0; i < SAGE_PIPE_MAX_DEPTH; ++i) { p->cap_count[i] = 0; p->cap_id[i] = 0; }
     return SAGE_OK;
 }
@@ -270,6 +495,7 @@ extern "C" int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64
 // Make `stream` wait for everything submitted so far (all four roles).
 extern "C" int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream) {
     SAGE_REQUIRE(p, "pipe_join: NULL pipe");
+    if (int rc = sage_pipe_flush(p)) return rc;
     if (p->submitted == 0) return SAGE_OK;
     hipStream_t st = (hipStream_t)stream;
     for (int r = 0; r < 4; ++r) {
@@ -290,6 +516,7 @@ extern "C" int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream) {
 // Fork: make every role stream wait for `stream` ("the inputs written there are ready").
 extern "C" int sage_pipe_fork(sage_pipe_t* p, sage_stream_t stream) {
     SAGE_REQUIRE(p, "pipe_fork: NULL pipe");
+    if (int rc = sage_pipe_flush(p)) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e = p->ev_fork;
     bool recorded = false;

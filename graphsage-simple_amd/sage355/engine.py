@@ -460,8 +460,10 @@ class RolePipeline:
     `priorities`: per distinct stream, 0 = default, -1 = high (HIP stream priority; the latency-bound roles).
     The reference has no counterpart (model.py:240-252 is one batch at a time on the host)."""
 
-    def __init__(self, rowptr, col, table, w1, w2, k1, k2, batch, depth=4, roles="SGDL", priorities=None, streams=None, **engine_kwargs):
+    def __init__(self, rowptr, col, table, w1, w2, k1, k2, batch, depth=4, roles="SGDL", priorities=None, streams=None, threads=None,
+                 window=None, **engine_kwargs):
         import ctypes
+        import os
         if depth < 1 or depth > native.PIPE_MAX_DEPTH:
             raise native.SageError(f"RolePipeline: depth must be in [1, {native.PIPE_MAX_DEPTH}]")
         if len(roles) != 4:
@@ -491,6 +493,31 @@ class RolePipeline:
                      "pipe_create")
         self._wkey = self._weights_key()
         self._keep = []
+        # host enqueue threads (one per role stream; sage_pipe_set_threads): submit() then only posts the batch.  Opt-in (threads=True or
+        # SAGE_PIPE_THREADS=1), because a caller that synchronises the device itself must then flush() first; bench.py opts in
+        if threads is None:
+            threads = os.environ.get("SAGE_PIPE_THREADS", "0") == "1" and len(names) == 4
+        if window is None:
+            window = int(os.environ.get("SAGE_PIPE_WINDOW", "0"))
+        self.threads, self._window = False, int(window)
+        if threads:
+            self.set_threads(True, window)
+
+    def set_threads(self, on, window=None):
+        """Start (or drain and stop) the four host enqueue threads.  `window` > 0: role S enqueues batch b only once batch
+        b - window has left the GPU (bounds the host's run-ahead); None keeps the pipe's setting."""
+        if window is not None:
+            self._window = int(window)
+        native.check(native.lib().sage_pipe_set_threads(self._h, 1 if on else 0, self._window), "pipe_set_threads")
+        self.threads = bool(on)
+
+    def flush(self):
+        """Every submitted batch has been ENQUEUED on the role streams (host enqueue threads; a no-op without them).  Call it
+        before synchronising the device or the role streams yourself; join() / synchronize() do."""
+        rc = native.lib().sage_pipe_flush(self._h)
+        if rc != 0:
+            self._broken = rc == native.ELAUNCH
+            native.check(rc, "pipe_flush")
 
     def _check_usable(self):
         # a submit that failed between two of its enqueues leaves a batch half-way through the role streams, its workspace dirty and
@@ -514,6 +541,7 @@ class RolePipeline:
         h = getattr(self, "_h", None)
         if h:
             try:
+                native.lib().sage_pipe_flush(h)
                 torch.cuda.synchronize()
                 native.lib().sage_pipe_destroy(h)
             except Exception:
@@ -597,7 +625,11 @@ class RolePipeline:
         if stream is None:
             stream = getattr(self, "_cap_stream", None) or torch.cuda.Stream(device=self.device)
             self._cap_stream = stream
+        self.flush()
         torch.cuda.synchronize()
+        was_threaded = self.threads
+        if was_threaded:
+            self.set_threads(False)          # a capture records the calls of the capturing thread
         self.reset()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(stream):
@@ -606,9 +638,12 @@ class RolePipeline:
                 self.submit_many(seeds, keys, out, segment_start=True)
                 self.join(stream)
         self.reset()
+        if was_threaded:
+            self.set_threads(True)
         self._keep.append((seeds, out))
         return g, stream
 
     def synchronize(self):
+        self.flush()
         for s in self._streams.values():
             s.synchronize()

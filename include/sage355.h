@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 3
+#define SAGE_ABI_VERSION 4
 
 #define SAGE_OK            0
 #define SAGE_EINVAL       -1   /* bad argument (NULL, size, alignment, range) */
@@ -387,7 +387,12 @@ int sage_prepare_weights(const float* weight, int64_t ldw, int32_t dim, int32_t 
  * edge L(b) -> S(b + depth) is added as an explicit node dependency, because waiting for it by event crashes
  * hipStreamEndCapture on ROCm 7.2 (csrc/sage_pipe.hip, experiments/r03/capture_repro.cpp).  The captured graph embeds the seeds
  * pointers and keys of the batches it was captured with.  After a capture, call sage_pipe_reset before eager submission.
- * Not thread safe per pipe.
+ * Host enqueue threads (ABI 4): sage_pipe_set_threads(p, 1, window) starts one host thread per role; a submit then only POSTS the
+ * batch and each role's thread makes that role's HIP calls on its stream (thirteen HIP calls per batch are 40-60 us on one host
+ * thread -- as long as the GPU's period), ordered across threads as hipEvent semantics need.  sage_pipe_flush returns when every
+ * posted batch has been enqueued (and reports a role thread's error); join / fork / reset / update_weights / destroy flush first.
+ * A caller that synchronises the DEVICE or the role streams itself must flush first.  Needs four distinct role streams.
+ * Not thread safe per pipe (one submitting thread).
  * Replaces nothing in the reference (model.py:240-252 runs one batch at a time).
  * ------------------------------------------------------------------------- */
 #define SAGE_PIPE_MAX_DEPTH 8
@@ -414,6 +419,11 @@ int sage_pipe_join(sage_pipe_t* p, sage_stream_t stream);
 int sage_pipe_fork(sage_pipe_t* p, sage_stream_t stream);
 /* Forget every submit (the next `depth` submits find their workspaces free); the caller has joined / synchronised all of them. */
 int sage_pipe_reset(sage_pipe_t* p);
+/* on != 0: start the four host enqueue threads (on == 0: drain and stop them).  window > 0: role S enqueues batch b only once batch
+ * b - window has left the GPU, which bounds how far the host runs ahead (0 = unbounded; window < 32). */
+int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window);
+/* Every posted batch has been enqueued on the role streams (not: has run).  Returns the first error a role thread met. */
+int sage_pipe_flush(sage_pipe_t* p);
 
 #ifdef __cplusplus
 }

@@ -32,10 +32,10 @@ def oracle_two_hop(graph, table, w1, w2, seeds, k1, k2, key, concat=False):
     return ref_sparse.two_hop_forward(table, w1, w2, seeds, nbr2, cnt2, s1, nbr1, cnt1, gcn=not concat, **kw), len(s1), int(cnt1.sum())
 
 
-@pytest.mark.parametrize("relabel,depth", [("degree", 4), (None, 8)])
-def test_role_pipeline_at_config3_size_against_the_oracle(relabel, depth):
+@pytest.mark.parametrize("relabel,depth,threads", [("degree", 4, True), ("degree", 4, False), (None, 8, False)])
+def test_role_pipeline_at_config3_size_against_the_oracle(relabel, depth, threads):
     """configs[2]: R-MAT 2^20 / 16 M edges, D0 = 256, H = 128/128, fanout 15/25, B = 4096; SGDL, depth 4 with the degree layout
-    (what bench.py times) and depth 8 in the caller's order; 2 * depth + 1 batches, so that every workspace is reused at least once.  Every batch's output: (a) bit-identical to the
+    and one host enqueue thread per role stream (what bench.py times), the same fed by the submitting thread alone, and depth 8 in the caller's order; 2 * depth + 1 batches, so that every workspace is reused at least once.  Every batch's output: (a) bit-identical to the
     single-stream forward of the same (seeds, key); (b) within 1e-5 of the row maximum of the oracle computed from the graph,
     the seeds and the key only."""
     graph = rmat_graph(20, 16_000_000, seed=0, cache_dir=CACHE)
@@ -52,7 +52,8 @@ def test_role_pipeline_at_config3_size_against_the_oracle(relabel, depth):
     keys = [0x5A6E355 + i for i in range(nb)]
     rowptr, col = graph.to(DEV)
     tdev, w1d, w2d = table.to(DEV), w1.to(DEV), w2.to(DEV)
-    pipe = RolePipeline(rowptr, col, tdev, w1d, w2d, k1, k2, batch=b, depth=depth, roles="SGDL", relabel=relabel)
+    pipe = RolePipeline(rowptr, col, tdev, w1d, w2d, k1, k2, batch=b, depth=depth, roles="SGDL", relabel=relabel, threads=threads)
+    assert pipe.threads == threads
     out = torch.empty(nb, b, h2, device=DEV)
     torch.cuda.synchronize()
     for i in range(nb):                                  # one host call per batch, as bench.py's timed loop
@@ -502,3 +503,58 @@ def test_engine_gradients_with_the_self_loop_aggregator_match_fp64_autograd(gcn)
     for name, g, r in zip(("w1", "w2", "w_cls"), grads, ref):
         err = (g.cpu().double() - r).abs().max().item() / r.abs().max().item()
         assert err <= 2e-5, f"grad {name}: max |g - ref| / max|ref| = {err:.2e}"
+
+
+# ------------------------------------------------------------------------------------------ host enqueue threads (sage_pipe_set_threads)
+@pytest.mark.parametrize("window,concat", [(0, False), (6, False), (3, True)])
+def test_role_pipeline_host_threads_are_bit_identical_over_a_long_run(window, concat):
+    """One host thread per role stream: 600 batches (more than the descriptor ring holds, so the poster has to wait for the role
+    threads; every workspace reused 150 times), with and without a bound on the host's run-ahead, gcn and concat encoders.
+    Every output equals the single-stream forward of the same (seeds, key); flush / join / reset / weight updates in between."""
+    from sage355 import native
+    graph = rmat_graph(14, 200_000, seed=3, cache_dir=CACHE)
+    gen = torch.Generator().manual_seed(5)
+    d0, h1, h2, k1, k2, b, nb = 64, 32, 16, 5, 7, 256, 600
+    mult = 2 if concat else 1
+    table = torch.randn(graph.num_nodes, d0, generator=gen).to(DEV)
+    w1 = ((torch.rand(h1, mult * d0, generator=gen) * 2 - 1) * 0.2).to(DEV)
+    w2 = ((torch.rand(h2, mult * h1, generator=gen) * 2 - 1) * 0.2).to(DEV)
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    rs = np.random.default_rng(2)
+    seeds = torch.from_numpy(np.stack([rs.choice(cand, b, replace=False) for _ in range(nb)]).astype(np.int32)).to(DEV)
+    keys = [77 + 13 * i for i in range(nb)]
+    rowptr, col = graph.to(DEV)
+    pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=4, roles="SGDL", concat=concat, threads=True, window=window)
+    eng = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, concat=concat)
+    out = torch.empty(nb, b, h2, device=DEV)
+    torch.cuda.synchronize()
+    for i in range(nb):
+        pipe.submit(seeds[i], keys[i], out[i])
+    pipe.synchronize()                                   # flushes the role threads, then waits for the four streams
+    torch.cuda.synchronize()
+    for i in list(range(0, nb, 37)) + [nb - 1]:
+        assert torch.equal(out[i], eng.forward(seeds[i], seed=keys[i])), f"batch {i}"
+    # submit_many + join on the caller's stream, after a reset; then a weight update seen by the next batch
+    pipe.reset()
+    out2 = torch.empty(8, b, h2, device=DEV)
+    pipe.submit_many(seeds[:8], keys[:8], out2, segment_start=True)
+    pipe.join()
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out[:8])
+    with torch.no_grad():
+        w2.mul_(0.5)
+    pipe.submit(seeds[9], keys[9], out2[0])
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    eng.invalidate_weights()
+    assert torch.equal(out2[0], eng.forward(seeds[9], seed=keys[9]))
+    assert not torch.equal(out2[0], out[9])
+    # threads off again: the submitting thread makes the calls itself, same results
+    pipe.set_threads(False)
+    pipe.submit(seeds[9], keys[9], out2[1])
+    torch.cuda.synchronize()
+    assert torch.equal(out2[1], out2[0])
+    # the threads need four distinct role streams
+    shared = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=2, roles="SGDD", concat=concat)
+    with pytest.raises(native.SageError, match="four distinct role streams"):
+        shared.set_threads(True)
