@@ -44,8 +44,24 @@ const sage_tunables_t& sage_tunables() {
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);
         x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);
+        x.dense_pc = env_int("SAGE_DENSE_PC", 0, 0, 1);
         x.tile16_waves = env_int("SAGE_T16_WAVES", 8, 8, 16) >= 16 ? 16 : 8;
         return x;
     }();
     return t;
+}
+
+// Run-time options (the launch tunables above are read once per process): "dense_pc" -- 1 / 0 switches the contraction of rows <= 256
+// floats wide to the producer / consumer kernel and back, -1 returns to the SAGE_DENSE_PC default.  Tests run both kernels in one process.
+static int g_dense_pc_override = -1;
+int sage_dense_pc_enabled() { return g_dense_pc_override >= 0 ? g_dense_pc_override : sage_tunables().dense_pc; }
+extern "C" int sage_set_option(const char* name, int32_t value) {
+    SAGE_REQUIRE(name, "set_option: NULL name");
+    if (strcmp(name, "dense_pc") == 0) {
+        SAGE_REQUIRE(value >= -1 && value <= 1, "set_option: dense_pc = %d outside [-1, 1]", value);
+        g_dense_pc_override = value;
+        return SAGE_OK;
+    }
+    sage_set_error("set_option: unknown option '%s'", name);
+    return SAGE_EINVAL;
 }

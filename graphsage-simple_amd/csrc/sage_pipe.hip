@@ -243,7 +243,7 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
                                                  SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
             return rc;
 #endif
-        return record(p, RS, slot, p->st[RG] != p->st[RS]);
+        return record(p, RS, slot, p->st[RG] != p->st[RS] || p->st[RD] != p->st[RS]);   // G waits for it, and D may (self chunk of a two-launch contraction)
     case RG:
         // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
         if (int rc = wait_on(p, RG, RS, slot)) return rc;
@@ -254,7 +254,14 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
         if (d.gev[1] && hipEventRecord((hipEvent_t)d.gev[1], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
         return record(p, RG, slot, p->st[RD] != p->st[RG]);
     case RD:
-        // D: the contraction (or the whole fused layer 1)
+        // D: the contraction (or the whole fused layer 1).  The 512-deep concat layer is two launches: the nodes' own rows' chunk needs
+        // the sampling only and runs BESIDE the gather; the means' chunk adds itself to those partial sums once the gather is done
+#ifndef SAGE_PIPE_SKIP_D
+        if (sage_forward2_has_self_stage(m, ws, p->ws_bytes, p->batch)) {
+            if (int rc = wait_on(p, RD, RS, slot)) return rc;
+            if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1_SELF, p->st[RD])) return rc;
+        }
+#endif
         if (int rc = wait_on(p, RD, RG, slot)) return rc;
 #ifndef SAGE_PIPE_SKIP_D
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;

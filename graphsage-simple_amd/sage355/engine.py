@@ -73,7 +73,8 @@ class TwoHopEngine:
         import os
         self._table_sliced = _shared_sliced
         self._table_sliced_version = self.table._version
-        self._want_sliced = slice_major is True or (slice_major == "auto" and not concat and os.environ.get("SAGE_TABLE_SLICED", "1") != "0")
+        _sl = os.environ.get("SAGE_TABLE_SLICED", "1")              # 0: never, 1: "auto" as above, 2: "auto" includes the concat encoder (A/B)
+        self._want_sliced = slice_major is True or (slice_major == "auto" and (_sl == "2" or (not concat and _sl != "0")))
         self._wpad_key = None
         self._w1p = self._w2p = None
         self._w1prep = self._w1prep_key = None

@@ -425,6 +425,11 @@ int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window);
 /* Every posted batch has been enqueued on the role streams (not: has run).  Returns the first error a role thread met. */
 int sage_pipe_flush(sage_pipe_t* p);
 
+/* Run-time options (ABI 4).  "dense_pc": 1 = contract rows of <= 256 floats with the producer / consumer kernel (csrc/sage_dense.hip,
+ * dense_pc_kernel; needs prepared weight planes), 0 = with the lock-step kernel, -1 = the SAGE_DENSE_PC environment default (0).
+ * Not thread safe against concurrent launches.  Replaces nothing in the reference. */
+int sage_set_option(const char* name, int32_t value);
+
 #ifdef __cplusplus
 }
 #endif
