@@ -85,6 +85,8 @@ def parse():
                          "the four streams are fed in parallel); 0 = the submitting thread makes all thirteen HIP calls of a batch itself")
     ap.add_argument("--window", type=int, default=int(os.environ.get("SAGE_PIPE_WINDOW", "0")),
                     help="pipe with host threads: role S enqueues batch b only once batch b - window has left the GPU (0 = unbounded)")
+    ap.add_argument("--high-priority", default=os.environ.get("SAGE_PIPE_PRIO", ""),
+                    help="pipe: role letters whose streams get HIP's high stream priority, e.g. DL (default: none)")
     ap.add_argument("--roles", default=os.environ.get("SAGE_ROLES", "SGDL"), help="pipe: roles S,G,D,L -> streams, e.g. SGDL, SGDD")
     ap.add_argument("--batches-per-replay", type=int, default=0,
                     help="queued batches embedded in one hipGraph replay (0 = preset: 1, or 10 for the 256-seed Pubmed configuration, "
@@ -309,6 +311,7 @@ def main():
     pipe_graphs = None
     if exec_mode in ("pipe", "pipegraph"):
         pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles,
+                            priorities={ch: -1 for ch in args.high_priority},
                             threads=bool(args.host_threads) and exec_mode == "pipe" and len(set(args.roles)) == 4, window=args.window, **ekw)
         pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
         torch.cuda.synchronize()
