@@ -104,8 +104,21 @@ static unsigned event_flags() {
 }
 #define kEventFlags event_flags()
 
-int wait_on(sage_pipe* p, int consumer, int producer, int slot) {
+// A producer that has already FINISHED needs no wait packet in the consumer's queue: the event is asked first (its most recent record
+// is the producer's record for this batch: the host order of the calls guarantees it) and a completed one is skipped.  In steady state
+// that is every S -> G hand-off (the samplers run batches ahead of the gather): one barrier packet less per batch in the gather's queue.
+// Never while capturing (an event query is not a capturable operation).  SAGE_PIPE_QUERY=0 turns it off (A/B).
+// Measured (experiments/r03/call43.sh): nothing in steady state, where the host runs batches ahead of the GPU and finds no event
+// complete (59.1 vs 59.2 us); 64.9 vs 65.8 us in the 20-step form, whose first batches are enqueued on an idle GPU.
+// (Making it ALWAYS true -- role threads that enqueue only once their producer has finished, so no queue ever holds a wait packet --
+// was measured too: 60.3 vs 59.0 us, call44.sh: the wait packets are not what separates consecutive kernels of a stream.)
+static bool query_first() {
+    static const bool on = [] { const char* v = getenv("SAGE_PIPE_QUERY"); return !(v && *v == '0'); }();
+    return on;
+}
+int wait_on(sage_pipe* p, int consumer, int producer, int slot, bool capturing = false) {
     if (p->st[consumer] == p->st[producer]) return SAGE_OK;          // stream order already says it
+    if (!capturing && query_first() && hipEventQuery(p->ev[producer][slot]) == hipSuccess) return SAGE_OK;
     if (hipStreamWaitEvent(p->st[consumer], p->ev[producer][slot], 0) != hipSuccess) {
         sage_set_error("pipe: hipStreamWaitEvent failed");
         return SAGE_ELAUNCH;
@@ -233,7 +246,7 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
             } else {
                 SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset "
                                                    "(after synchronising) before submitting eagerly again");
-                if (int rc = wait_on(p, RS, RL, slot)) return rc;
+                if (int rc = wait_on(p, RS, RL, slot, cap != 0)) return rc;
             }
         }
 #ifndef SAGE_PIPE_SKIP_S   // diagnostic builds only (experiments/ab_build.sh).  _G and _D may be skipped alone (stale data downstream); _S and _L
@@ -246,7 +259,7 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
         return record(p, RS, slot, p->st[RG] != p->st[RS] || p->st[RD] != p->st[RS]);   // G waits for it, and D may (self chunk of a two-launch contraction)
     case RG:
         // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
-        if (int rc = wait_on(p, RG, RS, slot)) return rc;
+        if (int rc = wait_on(p, RG, RS, slot, cap != 0)) return rc;
         if (d.gev[0] && hipEventRecord((hipEvent_t)d.gev[0], p->st[RG]) != hipSuccess) { sage_set_error("pipe: hipEventRecord failed"); return SAGE_ELAUNCH; }
 #ifndef SAGE_PIPE_SKIP_G   // diagnostic builds (experiments/ab_build.sh): the pipeline without one of its stages' kernels, stale data downstream
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG])) return rc;
@@ -258,18 +271,18 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
         // the sampling only and runs BESIDE the gather; the means' chunk adds itself to those partial sums once the gather is done
 #ifndef SAGE_PIPE_SKIP_D
         if (sage_forward2_has_self_stage(m, ws, p->ws_bytes, p->batch)) {
-            if (int rc = wait_on(p, RD, RS, slot)) return rc;
+            if (int rc = wait_on(p, RD, RS, slot, cap != 0)) return rc;
             if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1_SELF, p->st[RD])) return rc;
         }
 #endif
-        if (int rc = wait_on(p, RD, RG, slot)) return rc;
+        if (int rc = wait_on(p, RD, RG, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_D
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
 #endif
         return record(p, RD, slot, p->st[RL] != p->st[RD]);
     default:
         // L: layer 2; afterwards the workspace is clean again
-        if (int rc = wait_on(p, RL, RD, slot)) return rc;
+        if (int rc = wait_on(p, RL, RD, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_L
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
 #endif
