@@ -325,12 +325,12 @@ def test_training_schedule_is_bitwise_reproducible_eager_and_captured(gcn, relab
 
     (t1, l1), (t2, l2) = eager_run(), eager_run()
     assert l1 == l2, (l1, l2)
-    for a, c in zip(t1.parameters(), t2.parameters()):
-        assert torch.equal(a, c), "two eager runs of the same schedule differ"
+    for name, a, c in zip(("w1", "w2", "w_cls"), t1.parameters(), t2.parameters()):
+        assert torch.equal(a, c), f"two eager runs of the same schedule differ in {name}: {(a - c).abs().max().item():.3e} at {int((a != c).sum())} elements"
     (c1, l3), (c2, l4) = captured_run(), captured_run()
     assert l3 == l4, (l3, l4)
-    for a, c in zip(c1.parameters(), c2.parameters()):
-        assert torch.equal(a, c), "two captured runs of the same schedule differ"
+    for name, a, c in zip(("w1", "w2", "w_cls"), c1.parameters(), c2.parameters()):
+        assert torch.equal(a, c), f"two captured runs of the same schedule differ in {name}: {(a - c).abs().max().item():.3e} at {int((a != c).sum())} elements"
     np.testing.assert_allclose(l3, l1, rtol=1e-6)
     for name, a, c in zip(("w1", "w2", "w_cls"), c1.parameters(), t1.parameters()):
         err = (a - c).abs().max().item() / c.abs().max().item()
