@@ -126,6 +126,20 @@ def run_training(feat_data, labels, adj_lists, num_classes, seed=1, epochs=1, ba
     return res
 
 
+def _sum_over_batch(g_scores, emb, piece=256):
+    """g_scores^T . emb = [C, B] x [B, H] with the reduction over B in a FIXED order: 256-row pieces as one batched product, their
+    sum over the piece index by torch.sum (one thread per output element adds them in index order), a ragged tail last."""
+    b = g_scores.shape[0]
+    whole = (b // piece) * piece
+    if whole <= piece:
+        return g_scores.t() @ emb
+    n = whole // piece
+    acc = torch.bmm(g_scores[:whole].view(n, piece, -1).transpose(1, 2), emb[:whole].view(n, piece, -1)).sum(0)
+    if whole < b:
+        acc = acc + g_scores[whole:].t() @ emb[whole:]
+    return acc
+
+
 class EngineTrainer:
     """One SGD step of SupervisedGraphSage (model.py:52-69, 240-252: forward, CrossEntropy, backward, SGD lr 0.7) with NOTHING
     on the host but enqueues: device sampler at both hops and both layers through TwoHopEngine (sage_forward2), the classifier and
@@ -191,13 +205,20 @@ class EngineTrainer:
             b = seeds.shape[0]
             out = e.forward(seeds, seed=key)                               # sample, frontier, sample, layer 1, layer 2
         # classifier + loss + their gradients: stock torch on the same stream (model.py:59-69)
-        emb = out.detach().requires_grad_(True)
-        w_cls = self.w_cls.detach().requires_grad_(True)
+        # The classifier's weight gradient is a [C, B] x [B, H2] product whose reduction runs over the BATCH: for B >= 1024 the BLAS behind
+        # torch.mm may split it and add the pieces with atomics, and two runs of one schedule then differ in the last bits of w_cls (seen
+        # once in four runs of the GPU suite, 1024-seed case only).  So autograd stops at the scores and the two small products are
+        # spelled out; the one over the batch is cut into 256-row pieces (one batched product) that are added in a fixed order.
+        # (Accumulating it in fp64 instead costs 0.2 ms per step: 0.31 -> 0.53 ms captured at config-3 size.)
+        emb = out.detach()
+        scores = (emb @ self.w_cls.detach().t()).requires_grad_(True)
         if global_batch is None:
-            loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels)
+            loss = nn.functional.cross_entropy(scores, labels)
         else:
-            loss = nn.functional.cross_entropy(emb @ w_cls.t(), labels, reduction="sum") / float(global_batch)
-        g_out, g_cls = torch.autograd.grad(loss, (emb, w_cls))
+            loss = nn.functional.cross_entropy(scores, labels, reduction="sum") / float(global_batch)
+        (g_scores,) = torch.autograd.grad(loss, (scores,))
+        g_out = g_scores @ self.w_cls.detach()                              # [B, C] x [C, H2]: reduction over the classes
+        g_cls = _sum_over_batch(g_scores, emb)                               # [C, B] x [B, H2]: reduction over the batch
         # both layers' weight gradients from the intermediates this forward left in the engine's workspace
         g_w1, g_w2 = e.backward_weights(out, g_out)
         return loss.detach(), (g_w1, g_w2, g_cls)
