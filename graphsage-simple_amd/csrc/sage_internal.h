@@ -98,7 +98,7 @@ struct sage_tunables_t {
                                   //                      three dependent rounds on 128-256 blocks instead of one round on 1500; pipeline 66.8 vs 66.2 us)
     int dense_pc;                 // SAGE_DENSE_PC        1: contraction with producer / consumer waves (dense_pc_kernel) when the weight planes are prepared
                                   //                      and rows are <= 256 wide; 0 (default): dense_bf16x3_kernel (all waves in lock step).  The producer /
-                                  //                      consumer kernel is faster alone (14.5 vs 17 us at config 3) and slower in the role pipeline (61.3 vs
+                                  //                      consumer kernel is faster alone (16.5 vs 17.7 us at config 3) and slower in the role pipeline (61.3 vs
                                   //                      59.7 us per forward; concat 116 vs 91): its block holds 2 x 248 of a SIMD's 512 VGPRs, so nothing
                                   //                      else fits on its CU, where the lock-step kernel's 2 x 168 leave room for the gather's waves
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks, default: 1.5 us per forward in the pipeline)

@@ -16,7 +16,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-OURS = ("sample_fused_kernel", "sample_kernel", "gather_mean", "dense_bf16x3_kernel", "dense_layer_kernel", "layer_tile16_kernel", "layer_fused_kernel",
+OURS = ("sample_fused_kernel", "sample_kernel", "gather_mean", "dense_bf16x3_kernel", "dense_pc_kernel", "dense_layer_kernel", "layer_tile16_kernel", "layer_fused_kernel",
         "linear_act_kernel", "prepare_weights_kernel")
 PEAK_F32_TF, PEAK_BF16_TF, SIMDS = 157.3, 2500.0, 1024
 
