@@ -201,3 +201,24 @@ def test_rmat_accelerated_integer_path_gives_the_same_csr():
     a = G.rmat_graph(13, 150_000, seed=3, accel=None, chunk=1 << 16)
     b = G.rmat_graph(13, 150_000, seed=3, accel="cpu", chunk=1 << 16)
     assert np.array_equal(a.rowptr, b.rowptr) and np.array_equal(a.col, b.col) and a.col.dtype == b.col.dtype == np.int32
+
+
+def test_classifier_gradient_is_summed_over_the_batch_in_a_fixed_order():
+    """train._sum_over_batch: g_scores^T . emb cut into 256-row pieces (one batched product) added in index order, a ragged tail
+    last -- the same value as the plain product up to fp32 rounding, for every batch size, and the plain product itself for
+    batches of at most 256 rows (model.py:247-250: the classifier's weight gradient of loss.backward())."""
+    import torch
+    from sage355.train import _sum_over_batch
+    gen = torch.Generator().manual_seed(0)
+    for b, c, h in [(4, 3, 8), (256, 7, 128), (257, 7, 128), (1024, 5, 32), (1100, 5, 32), (4096, 7, 128)]:
+        g, e = torch.randn(b, c, generator=gen), torch.randn(b, h, generator=gen)
+        ref = g.double().t() @ e.double()
+        got = _sum_over_batch(g, e)
+        assert got.shape == (c, h)
+        assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        if b <= 511:
+            assert torch.equal(got, g.t() @ e)
+        # piece by piece, by hand
+        if b % 256 == 0 and b > 256:
+            want = sum((g[i:i + 256].t() @ e[i:i + 256]).double() for i in range(0, b, 256))
+            assert (got.double() - want).abs().max().item() <= 1e-5 * ref.abs().max().item()
