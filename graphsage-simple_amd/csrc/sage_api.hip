@@ -4,6 +4,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "sage_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -53,13 +55,13 @@ const sage_tunables_t& sage_tunables() {
 
 // Run-time options (the launch tunables above are read once per process): "dense_pc" -- 1 / 0 switches the contraction of rows <= 256
 // floats wide to the producer / consumer kernel and back, -1 returns to the SAGE_DENSE_PC default.  Tests run both kernels in one process.
-static int g_dense_pc_override = -1;
-int sage_dense_pc_enabled() { return g_dense_pc_override >= 0 ? g_dense_pc_override : sage_tunables().dense_pc; }
+static std::atomic<int> g_dense_pc_override{-1};       // read by launches on the pipe's role threads
+int sage_dense_pc_enabled() { const int o = g_dense_pc_override.load(std::memory_order_relaxed); return o >= 0 ? o : sage_tunables().dense_pc; }
 extern "C" int sage_set_option(const char* name, int32_t value) {
     SAGE_REQUIRE(name, "set_option: NULL name");
     if (strcmp(name, "dense_pc") == 0) {
         SAGE_REQUIRE(value >= -1 && value <= 1, "set_option: dense_pc = %d outside [-1, 1]", value);
-        g_dense_pc_override = value;
+        g_dense_pc_override.store(value, std::memory_order_relaxed);
         return SAGE_OK;
     }
     sage_set_error("set_option: unknown option '%s'", name);
