@@ -558,3 +558,35 @@ def test_role_pipeline_host_threads_are_bit_identical_over_a_long_run(window, co
     shared = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=2, roles="SGDD", concat=concat)
     with pytest.raises(native.SageError, match="four distinct role streams"):
         shared.set_threads(True)
+
+
+# ------------------------------------------------------------------------------------------ the bench line's contract
+def test_bench_line_as_the_driver_runs_it_keeps_the_contract():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command; the CPU baseline's budget cut to 3 s here): ONE JSON
+    line on stdout with the contract's keys, BASELINE's metric on configs[2], `roofline` and `cpu_baseline` objects whose figures are
+    consistent with each other, the timed path's output checked bit for bit, and the 1e-5 parity gate passed."""
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--gpus", "1",
+                        "--steps", "20", "--warmup", "5", "--cpu-seconds", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("node-embeddings/sec") and d["unit"] == "embeddings/s" and d["higher_is_better"] is True
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["dtype"], d["data"], d["vs_baseline"]) == (1, 20, 5, "weak", "f32", "synthetic", None)
+    cfg = d["config"]
+    assert "BASELINE configs[2]" in cfg["workload"] and "model" not in cfg and cfg["batch_per_gpu"] == 4096 and cfg["fanout"] == [15, 25]
+    assert "host enqueue thread" in cfg["execution"]                       # the path the round-3 tests above check against the oracle
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert d["parity_max_err_vs_fp64_oracle"] <= 1e-5 and d["timed_path_check"]["bit_identical_to_oracle_gated_forward"] is True
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and 0.05 < ro["frac"] < 1.0
+    assert abs(ro["achieved"] - ro["bytes_per_launch"] / (ro["kernel_ms"] * 1e-3) / 1e9) <= 1e-2 * ro["achieved"]
+    assert ro["traffic"] is None or ro["traffic"] >= ro["bytes_per_launch"]           # PMC bytes past L2 cannot be below the algorithmic bytes
+    assert abs(ro["forward_frac"] - ro["forward_bytes"] / (d["ms_per_step"] * 1e-3) / 8e12) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "embeddings/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert d["value"] > 1000 * cb["value"]                                 # (a sanity bound, not a target)
