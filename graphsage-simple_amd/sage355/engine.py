@@ -12,6 +12,34 @@ from . import native
 from .ops import ACT_RELU, _chk, _need_gpu, _row_major, as_ids
 
 
+def pretransform_table(table, w1, rows_per_call=1 << 18):
+    """INFERENCE at fixed weights, gcn encoder (encoders.py:56-61 with gcn=True): the mean is linear, so
+    relu(W1 . mean(X[nbrs])) = relu(mean(Y[nbrs])) with Y = X . W1^T -- layer 1's contraction moves from every forward to weight-
+    preparation time (once per weight update: 2 N D0 H1 flop, ~1 ms for a million 256-wide rows), the gather reads rows of H1 floats
+    instead of D0 (half the bytes at 256 -> 128) and the per-batch contraction shrinks to H1 x H1.
+
+        y, eye = pretransform_table(table, w1)                       # [N, H1] fp32 on the table's device, identity [H1, H1]
+        eng = TwoHopEngine(rowptr, col, y, eye, w2, k1, k2)          # or RolePipeline(rowptr, col, y, eye, w2, ...)
+
+    The engine is used UNCHANGED: with W1 := I the split-bf16 contraction returns its operand exactly (x = hi + mid + lo times 1.0).
+    Same sampled sets as the plain engine for the same keys; values equal to a few fp32 roundings (the sums are associated
+    differently: mean of products instead of product of the mean) -- inside the 1e-5 parity bar, not bit-identical.  Differences by
+    construction: non-finite FEATURES meet W1 before the mean (Inf - Inf cases of torch.mm land elsewhere); training needs the plain
+    engine (Y is stale after every optimizer step; call this again after an update of W1).  Not for the concat encoder (two weight
+    halves meet different rows there).  Y is computed by this library's own fp32-accurate contraction (sage_linear_act)."""
+    from . import ops
+    _need_gpu()
+    if w1.dim() != 2 or table.dim() != 2 or w1.shape[1] != table.shape[1]:
+        raise native.SageError(f"pretransform_table: W1 {tuple(w1.shape)} does not fit a {table.shape[1]}-wide table (gcn encoder only)")
+    n, h1 = table.shape[0], w1.shape[0]
+    w = w1.detach().to(table.device, torch.float32).contiguous()
+    y = torch.empty((n, h1), dtype=torch.float32, device=table.device)
+    for lo in range(0, n, rows_per_call):
+        hi = min(n, lo + rows_per_call)
+        ops.linear_act(table[lo:hi], w, act=ops.ACT_NONE, out=y[lo:hi])
+    return y, torch.eye(h1, dtype=torch.float32, device=table.device)
+
+
 class TwoHopEngine:
     def __init__(self, rowptr, col, table, w1, w2, k1, k2, concat=False, agg_self_loop=False, act1=ACT_RELU,
                  act2=ACT_RELU, nan_empty=True, fused=True, max_batch=4096, rowptr_outer=None, col_outer=None, relabel=None,

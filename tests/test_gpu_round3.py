@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import ref_sparse, sampler_ref
+from sage355 import native as native_mod
 from sage355 import ops
 from sage355.engine import RolePipeline, TwoHopEngine
 from sage355.graph import relabel_by_degree, rmat_graph
@@ -590,3 +591,55 @@ def test_bench_line_as_the_driver_runs_it_keeps_the_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "embeddings/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 1000 * cb["value"]                                 # (a sanity bound, not a target)
+
+
+# ------------------------------------------------------------------------------------------ inference on a pre-transformed table
+@pytest.mark.parametrize("relabel,self_loop", [(None, False), ("degree", False), ("degree", True)])
+def test_pretransformed_table_inference_matches_the_oracle(relabel, self_loop):
+    """engine.pretransform_table: Y = X . W1^T once, then the UNCHANGED engine on (Y, identity, W2).  Same sampled sets as the plain
+    engine for the same keys (the sampler never looks at the table), values within the 1e-5 bar of the fp64 oracle of the ORIGINAL
+    problem (aggregators.py:54-74, encoders.py:56-61 on X and W1) and within a few fp32 roundings of the plain engine; the role
+    pipeline over the transformed table is bit-identical to its single forwards."""
+    from sage355.engine import pretransform_table
+    import test_gpu_round2 as r2
+    graph, table, w1, w2 = r2._problem(scale=15, edges=600_000, d0=256, h1=128, h2=64)
+    rowptr, col = graph.to(DEV)
+    tdev, w1d, w2d = table.to(DEV), w1.to(DEV), w2.to(DEV)
+    b, k1, k2 = 2048, 15, 25
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    seeds_host = np.random.default_rng(5).choice(cand, b, replace=False).astype(np.int32)
+    seeds = torch.from_numpy(seeds_host).to(DEV)
+    plain = TwoHopEngine(rowptr, col, tdev, w1d, w2d, k1, k2, max_batch=b, relabel=relabel, agg_self_loop=self_loop)
+    y, eye = pretransform_table(tdev, w1d)
+    assert y.shape == (graph.num_nodes, 128) and torch.equal(eye, torch.eye(128, device=DEV))
+    ref_y = (table.double() @ w1.double().t())
+    assert ((y.cpu().double() - ref_y).abs().max() / ref_y.abs().max()).item() < 1e-6          # the library's fp32-accurate contraction
+    pre = TwoHopEngine(rowptr, col, y, eye, w2d, k1, k2, max_batch=b, relabel=relabel, agg_self_loop=self_loop)
+    a = plain.forward(seeds, seed=77).clone()
+    ia = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in plain.intermediates().items()}
+    c = pre.forward(seeds, seed=77).clone()
+    ic = pre.intermediates()
+    assert ia["n_s1"] == ic["n_s1"] and torch.equal(ia["cnt2"], ic["cnt2"]) and torch.equal(ia["nbr2"], ic["nbr2"])
+    # the frontier's row order is arbitrary: compare the layer-1 samples by node
+    oa, oc = torch.argsort(ia["s1_nodes"]), torch.argsort(ic["s1_nodes"])
+    assert torch.equal(ia["s1_nodes"][oa], ic["s1_nodes"][oc]) and torch.equal(ia["nbr1"][oa], ic["nbr1"][oc])
+    scale = a.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    assert ((a - c).abs() / scale).max().item() < 5e-6
+    # the fp64 oracle of the original problem on the sets the GPU drew (ids are the engine's internal ones)
+    it = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in ic.items()}
+    first = it["first_frontier_row"]
+    seeds_int = seeds_host if pre._new_of_old is None else pre._new_of_old[seeds.long()].cpu().numpy()
+    ref = ref_sparse.two_hop_forward(plain.table.cpu(), w1, w2, seeds_int, it["nbr2"], it["cnt2"], it["s1_nodes"][first:], it["nbr1"][first:],
+                                     it["cnt1"][first:], gcn=True, agg_gcn=self_loop)
+    assert_close_rowmax(c.cpu(), ref, what="pre-transformed engine vs oracle")
+    # the throughput path over the transformed table
+    pipe = RolePipeline(rowptr, col, y, eye, w2d, k1, k2, batch=b, depth=3, relabel=relabel, agg_self_loop=self_loop, threads=True)
+    out = torch.empty(5, b, 64, device=DEV)
+    sd = torch.stack([seeds, seeds.flip(0), seeds.roll(3), seeds, seeds.roll(9)])
+    for i in range(5):
+        pipe.submit(sd[i], 100 + i, out[i])
+    pipe.synchronize()
+    for i in range(5):
+        assert torch.equal(out[i], pre.forward(sd[i], seed=100 + i))
+    with pytest.raises(native_mod.SageError):
+        pretransform_table(tdev, torch.zeros(128, 512, device=DEV))          # the concat encoder's [H1, 2 D0] weight: not supported
