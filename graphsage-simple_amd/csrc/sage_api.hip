@@ -67,3 +67,20 @@ extern "C" int sage_set_option(const char* name, int32_t value) {
     sage_set_error("set_option: unknown option '%s'", name);
     return SAGE_EINVAL;
 }
+
+// Device memory fills as a KERNEL, never as hipMemsetAsync: on ROCm 7.2 a small hipMemsetAsync captured into a hipGraph does what it
+// says on the FIRST replay and writes garbage (kernel-argument-like pointers) into its 16 bytes from the second replay on
+// (experiments/r03/memset_in_graph.py).  That memset zeroed the "W holds a huge value" word behind the prepared weight planes, so
+// from its second replay on a captured training step ran layer 1 through the exact fp32 cold path whenever the garbage's first word was
+// not 0 -- which is what made captured steps differ from eager ones in the last bits (and from one another, one process in three).
+// n_words 32-bit words of value v at p (4-byte aligned).
+__global__ void sage_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int sage_fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t st) {
+    if (n_words == 0) return SAGE_OK;
+    const int blocks = (int)(n_words < 256 ? 1 : (n_words / 256 < 1024 ? n_words / 256 : 1024));
+    hipLaunchKernelGGL(sage_fill_u32_kernel, dim3(blocks), dim3(256), 0, st, (uint32_t*)p, v, n_words);
+    SAGE_CHECK_LAUNCH("sage_fill_u32_kernel");
+    return SAGE_OK;
+}

@@ -248,10 +248,7 @@ extern "C" int sage_gather_mean_backward_ws(const float* grad_agg, int64_t ldg, 
         return SAGE_ELAUNCH;
     }
     // start == end == 0 for rows nobody points at (start and end are adjacent in the workspace: one memset)
-    if (hipMemsetAsync(start, 0, (size_t)((char*)end - (char*)start) + (size_t)table_rows * 4, st) != hipSuccess) {
-        sage_set_error("gather_mean_backward_ws: hipMemsetAsync failed");
-        return SAGE_ELAUNCH;
-    }
+    if (int rc = sage_fill_u32(start, 0u, ((size_t)((char*)end - (char*)start) + (size_t)table_rows * 4) / 4, st)) return rc;
     hipLaunchKernelGGL(det_heads_kernel, dim3(sage_cdiv(L.slots, 256)), dim3(256), 0, st, (const int32_t*)keys_out, L.slots, (int)table_rows, start, end);
     SAGE_CHECK_LAUNCH("det_heads_kernel");
     const int lg = dim >= 256 ? 64 : dim >= 128 ? 32 : dim >= 64 ? 16 : 8;

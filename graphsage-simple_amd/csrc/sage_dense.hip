@@ -1044,7 +1044,7 @@ extern "C" int sage_prepare_weights(const float* weight, int64_t ldw, int32_t di
     const int kp = prepared_kp(dim, out_dim);
     const int threads = (int)((need - 16) / (3 * 16)), blocks = sage_cdiv(threads, 256);      // one thread per (pass, wave, step, lane)
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync((char*)prepared + need - 16, 0, 16, st) != hipSuccess) { sage_set_error("prepare_weights: hipMemsetAsync failed"); return SAGE_ELAUNCH; }
+    if (int rc = sage_fill_u32((char*)prepared + need - 16, 0u, 4, st)) return rc;          // the "W holds a huge value" trailer (a kernel, not a memset: sage_api.hip)
     uint4* out = (uint4*)prepared;
     if (dim > 256) {
         if (concat) hipLaunchKernelGGL((prepare_weights_kernel<256, true, true>), dim3(blocks), dim3(256), 0, st, weight, ldw, dim, out_dim, out);

@@ -297,10 +297,7 @@ extern "C" int sage_forward2_init(const sage_model_t* m, void* workspace, size_t
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
     // smaller batches use a prefix of the key array with a smaller power-of-two capacity: wipe the largest
-    if (hipMemsetAsync(ws + L.counters, 0, 16 * sizeof(int32_t), st) != hipSuccess ||
-        hipMemsetAsync(ws + L.hash_keys, 0xFF, (size_t)L.hash_capacity * 4, st) != hipSuccess) {
-        sage_set_error("forward2_init: memset failed");
-        return SAGE_ELAUNCH;
-    }
+    if (int rc = sage_fill_u32(ws + L.counters, 0u, 16, st)) return rc;
+    if (int rc = sage_fill_u32(ws + L.hash_keys, 0xFFFFFFFFu, (size_t)L.hash_capacity, st)) return rc;
     return SAGE_OK;
 }

@@ -103,6 +103,8 @@ struct sage_tunables_t {
                                   //                      else fits on its CU, where the lock-step kernel's 2 x 168 leave room for the gather's waves
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks, default: 1.5 us per forward in the pipeline)
 };
+// n_words 32-bit words := v, as a kernel (hipMemsetAsync misbehaves inside replayed hipGraphs on ROCm 7.2: sage_api.hip)
+int sage_fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t st);
 const sage_tunables_t& sage_tunables();
 int sage_dense_pc_enabled();          // SAGE_DENSE_PC, or what sage_set_option("dense_pc", ...) last said
 

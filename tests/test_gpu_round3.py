@@ -288,10 +288,10 @@ def test_mean_backward_through_the_inverted_index_matches_autograd_and_is_reprod
 @pytest.mark.parametrize("gcn,relabel,hidden1,d0", [(True, None, 64, 128), (False, "degree", 64, 128), (True, "degree", 30, 66), (True, None, 128, 256)])
 def test_training_schedule_is_bitwise_reproducible_eager_and_captured(gcn, relabel, hidden1, d0):
     """Six SGD steps over a ring of four mini-batches: eager twice, captured (ONE hipGraph per step, replayed six times) twice.
-    Two eager runs agree BIT FOR BIT in every loss and weight, and so do two captured runs (round 2: fp32 atomics in both backward
-    kernels, and a weight gradient that depended on the frontier's arbitrary row order).  Captured against eager: the losses agree
-    to 1e-6, the weights to 1e-5 of their largest element -- a difference of the last bits that appears in w_cls too, whose gradient
-    never passes through this library (stock torch ops under capture; experiments/r03/cap_diag.py)."""
+    Two eager runs agree BIT FOR BIT in every loss and weight, so do two captured runs, and so do captured and eager (round 2: fp32
+    atomics in both backward kernels, and a weight gradient that depended on the frontier's arbitrary row order; round 3: a captured
+    hipMemsetAsync that went wrong from its second replay on, and the classifier's gradient left to the BLAS's split of a long
+    reduction)."""
     from sage355.train import EngineTrainer
     graph = rmat_graph(14, 300_000, seed=4, accel=None)
     gen = torch.Generator().manual_seed(1)
@@ -332,10 +332,12 @@ def test_training_schedule_is_bitwise_reproducible_eager_and_captured(gcn, relab
     assert l3 == l4, (l3, l4)
     for name, a, c in zip(("w1", "w2", "w_cls"), c1.parameters(), c2.parameters()):
         assert torch.equal(a, c), f"two captured runs of the same schedule differ in {name}: {(a - c).abs().max().item():.3e} at {int((a != c).sum())} elements"
-    np.testing.assert_allclose(l3, l1, rtol=1e-6)
+    # captured against eager: bit for bit as well, since the end of round 3 (until then a 16-byte hipMemsetAsync inside the captured step
+    # -- the "W holds a huge value" word behind the prepared weight planes -- wrote garbage from its second replay on, ROCm 7.2, and
+    # sent layer 1 through the exact fp32 cold path: last-bit differences, experiments/r03/memset_in_graph.py)
+    assert l3 == l1, (l3, l1)
     for name, a, c in zip(("w1", "w2", "w_cls"), c1.parameters(), t1.parameters()):
-        err = (a - c).abs().max().item() / c.abs().max().item()
-        assert err <= 1e-5, f"{name}: captured vs eager {err:.2e}"
+        assert torch.equal(a, c), f"{name}: captured vs eager differ: {(a - c).abs().max().item():.3e} at {int((a != c).sum())} elements"
     assert all(np.isfinite(l1)) and not all(x == l1[0] for x in l1)
 
 
@@ -555,6 +557,19 @@ def test_role_pipeline_host_threads_are_bit_identical_over_a_long_run(window, co
     pipe.submit(seeds[9], keys[9], out2[1])
     torch.cuda.synchronize()
     assert torch.equal(out2[1], out2[0])
+    # a capture in between: the threads step aside (a capture records the calls of the capturing thread) and come back
+    pipe.set_threads(True)
+    out3 = torch.empty(6, b, h2, device=DEV)
+    g, cap_stream = pipe.capture(seeds[20:26], keys[20:26], out3)
+    assert pipe.threads
+    with torch.cuda.stream(cap_stream):
+        g.replay()
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(out3[i], eng.forward(seeds[20 + i], seed=keys[20 + i])), f"captured batch {i}"
+    pipe.submit(seeds[30], keys[30], out2[2])            # eager again, through the threads
+    pipe.synchronize()
+    assert torch.equal(out2[2], eng.forward(seeds[30], seed=keys[30]))
     # the threads need four distinct role streams
     shared = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=2, roles="SGDD", concat=concat)
     with pytest.raises(native.SageError, match="four distinct role streams"):
