@@ -112,8 +112,9 @@ def test_engine_step_at_config3_size_gradients_and_step_time():
 @pytest.mark.parametrize("gcn,relabel,hidden1", [(True, None, 64), (False, "degree", 64), (True, None, 30)])
 def test_captured_step_trains_like_the_eager_step(gcn, relabel, hidden1):
     """EngineTrainer.capture_step: forward + loss + backward + SGD of the batch at the queue cursor as ONE hipGraph.  Replaying it
-    over a ring of mini-batches must leave the weights an eager loop over the same batches and keys leaves (fp32 atomics in the
-    weight gradient: equal up to summation order), wrap around the ring, and report the same losses."""
+    over a ring of mini-batches must leave the weights an eager loop over the same batches and keys leaves -- bit for bit since the
+    end of round 3 (no float atomics on the path, fills as kernels: a captured hipMemsetAsync went wrong from its second replay on) --
+    wrap around the ring, and report the same losses."""
     graph = rmat_graph(13, 150_000, seed=4, accel=None)
     gen = torch.Generator().manual_seed(1)
     table = torch.randn(graph.num_nodes, 128, generator=gen).to(DEV)
@@ -143,11 +144,10 @@ def test_captured_step_trains_like_the_eager_step(gcn, relabel, hidden1):
     for i in range(6):
         cap.replay_step()
         cap_losses.append(float(loss))
-    np.testing.assert_allclose(cap_losses, eager_losses, rtol=2e-4)
+    assert cap_losses == eager_losses, (cap_losses, eager_losses)
     assert all(np.isfinite(cap_losses)) and (hidden1 != 64 or cap_losses[-1] < cap_losses[0])
     for name, a, b in zip(("w1", "w2", "w_cls"), cap.parameters(), eager.parameters()):
-        err = (a - b).abs().max().item() / b.abs().max().item()
-        assert err <= 1e-4, f"{name}: captured vs eager {err:.2e}"
+        assert torch.equal(a, b), f"{name}: captured vs eager differ by {(a - b).abs().max().item():.3e} at {int((a != b).sum())} elements"
     # a replay moves the weights but not their version counters; an EAGER forward after it (validation) must run on
     # W_t, not on padded copies / bf16 planes of W_{t-1}: bit-identical to a fresh engine built from the trainer's weights
     from sage355.engine import TwoHopEngine
