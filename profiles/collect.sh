@@ -14,7 +14,10 @@ timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > "$O/be
 timeout -k 10 300 python bench.py --cpu-seconds 0 --engine-layout input > "$O/bench_layout_input.json" 2> "$O/bench_layout_input.err"
 timeout -k 10 300 python bench.py --cpu-seconds 0 --exec replay --streams 2 > "$O/bench_replay2.json" 2> "$O/bench_replay2.err"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --cpu-seconds 0 \
+# (--no-variant: the variants' pipelines -- caller's node order, pre-transformed table -- launch the same kernels on other data and
+#  would be averaged into the per-kernel summary)
+rm -rf "$O/stats"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --cpu-seconds 0 --no-variant \
     > "$O/bench_under_rocprof.json" 2> "$O/stats.log"; echo "stats rc=$?"
 # the same kernels with ONE batch in flight (host-enqueued on one stream): what each costs alone
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_alone" -- python3 "$R/bench.py" --exec direct --streams 1 \
