@@ -179,10 +179,20 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
         return rc;
     SAGE_EV(3);
     }
+    // serving on a pre-transformed table (sage_model_t.w1_is_identity): the split layer's gather applies act1 and writes h1; no contraction
+    const bool gather_only1 = split1 && m->w1_is_identity != 0 && !m->concat && m->d0 == m->h1 &&
+                              sage_gather_is_sliced(m->d0, m->table_ld, m->h1, m->table, h1, L.max_s1, m->k1);
     // 3. layer 1 on S1: the HBM-bound gather ...
     if (stages & SAGE_STAGE_GATHER1) {
     SAGE_EV(4);
-    if (split1) {
+    if (gather_only1) {
+        const int sw = m->table_slice_floats ? m->table_slice_floats : 64;
+        const bool sm = m->table_sliced != nullptr && (sw == 32 || sw == 64 || sw == 128) && m->d0 % sw == 0 && sage_aligned(m->table_sliced, 16);
+        if (int rc = sage_launch_gather_mean(sm ? m->table_sliced : m->table, m->num_nodes, sm ? sw : m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1,
+                                             s1_count, nullptr, self_loop ? s1_nodes : nullptr, nan1, h1, m->h1, first_row, st,
+                                             sm ? m->num_nodes * (int64_t)sw : 0, m->act1))
+            return rc;
+    } else if (split1) {
         // optional slice-major copy of the table ([d0 / 64][num_nodes][64]): every XCD pair reads ONE contiguous array
         const int sw = m->table_slice_floats ? m->table_slice_floats : 64;
         const bool sm = m->table_sliced != nullptr && (sw == 32 || sw == 64 || sw == 128) && m->d0 % sw == 0 && sage_aligned(m->table_sliced, 16);
@@ -205,7 +215,9 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     }
     if (stages & SAGE_STAGE_CONTRACT1) {
     SAGE_EV(6);
-    if (split1) {
+    if (gather_only1) {
+        // nothing: the gather wrote h1
+    } else if (split1) {
         const int parts = (two_launch && !(stages & SAGE_STAGE_CONTRACT1_SELF)) ? SAGE_DENSE_PART_AGG : SAGE_DENSE_PART_ALL;
         if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
                                              s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, m->w1_prepared, st, parts))

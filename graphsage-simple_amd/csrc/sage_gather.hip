@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_kernel(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, int64_t slice_stride) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, int64_t slice_stride, int act) {
     gather_sliced_block<SL>(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice,
-                            (int)blockIdx.x, (int)gridDim.x, slice_stride);
+                            (int)blockIdx.x, (int)gridDim.x, slice_stride, act);
 }
 
 using sage_gather_detail::gather_sliced_block_pipelined;
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void gather_mean_sliced_pipe_kernel(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, int64_t slice_stride) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, int64_t slice_stride, int act) {
     gather_sliced_block_pipelined<SL, U, R>(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo,
-                                         n_off, nslice, (int)blockIdx.x, (int)gridDim.x, slice_stride);
+                                         n_off, nslice, (int)blockIdx.x, (int)gridDim.x, slice_stride, act);
 }
 
 using sage_gather_detail::gather_sliced_block_rows;
@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void gather_mean_rows_kernel(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, int64_t slice_stride) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, int64_t slice_stride, int act) {
     gather_sliced_block_rows<SL, TRIP, SLOT>(table, table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo,
-                                       n_off, nslice, (int)blockIdx.x, (int)gridDim.x, slice_stride);
+                                       n_off, nslice, (int)blockIdx.x, (int)gridDim.x, slice_stride, act);
 }
 
 template <int SL, typename... A>
@@ -153,7 +153,7 @@ bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* ta
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
-                            hipStream_t st, int64_t slice_stride) {
+                            hipStream_t st, int64_t slice_stride, int act) {
     if (n == 0) return SAGE_OK;
     if (slice_stride != 0 || sage_gather_is_sliced(dim, ld, ldo, table, out, n, k)) {
         // 256-B slices (16 lanes; 512-B rows: 29.1 us as two slices vs 32.5 us as one).  A narrow row that does not end
@@ -176,9 +176,9 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
         const int blocks = nslice * max(1, kNumCU * sage_tunables().gather_blocks_per_cu / nslice);   // >= one block per slice (very wide rows)
         if (variant == 2) {
             // one destination row per lane group (see sage_gather_body.h)
-            if (sl == 8) launch_rows<8>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-            else if (sl == 32) launch_rows<32>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-            else launch_rows<16>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+            if (sl == 8) launch_rows<8>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+            else if (sl == 32) launch_rows<32>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+            else launch_rows<16>(blocks, slot_rows != nullptr, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
             SAGE_CHECK_LAUNCH("gather_mean_rows_kernel");
             return SAGE_OK;
         }
@@ -187,35 +187,36 @@ int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, 
             // next row's ids requested meanwhile.  U by fanout; lists longer than U x 64/sl take further trips.
             const int per = kWave / sl, need = sage_cdiv(k, per);
             if (sl == 64) {     // whole 1-KiB rows, one neighbour per wave-instruction: graphs with little reuse (every row read once)
-                if (need <= 8) launch_pipe<64, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-                else launch_pipe<64, 16>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                if (need <= 8) launch_pipe<64, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+                else launch_pipe<64, 16>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
             } else if (sl == 8) {
-                if (need <= 2) launch_pipe<8, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-                else if (need <= 4) launch_pipe<8, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-                else launch_pipe<8, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                if (need <= 2) launch_pipe<8, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+                else if (need <= 4) launch_pipe<8, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+                else launch_pipe<8, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
             } else if (sl == 32) {
-                if (need <= 4) launch_pipe<32, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-                else launch_pipe<32, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                if (need <= 4) launch_pipe<32, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+                else launch_pipe<32, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
             } else {
-                if (need <= 2) launch_pipe<16, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-                else if (need <= 4) launch_pipe<16, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
-                else launch_pipe<16, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                if (need <= 2) launch_pipe<16, 2>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+                else if (need <= 4) launch_pipe<16, 4>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
+                else launch_pipe<16, 8>(blocks, st, table, (int)table_rows, ld, dim, nbr, cnt, k, n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
             }
             SAGE_CHECK_LAUNCH("gather_mean_sliced_pipe_kernel");
             return SAGE_OK;
         }
         if (sl == 32)
             hipLaunchKernelGGL(gather_mean_sliced_kernel<32>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
-                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
         else if (sl == 8)
             hipLaunchKernelGGL(gather_mean_sliced_kernel<8>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
-                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
         else
             hipLaunchKernelGGL(gather_mean_sliced_kernel<16>, dim3(blocks), dim3(256), 0, st, table, (int)table_rows, ld, dim, nbr, cnt, k,
-                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride);
+                               n, n_dev, slot_rows, self_row, any_nonempty, out, ldo, n_off, nslice, slice_stride, act);
         SAGE_CHECK_LAUNCH("gather_mean_sliced_kernel");
         return SAGE_OK;
     }
+    if (act != SAGE_ACT_NONE) { sage_set_error("gather_mean: an activation in the epilogue exists in the column-sliced forms only"); return SAGE_EUNSUPPORTED; }
     const int blocks = min(sage_cdiv(n, 4), kNumCU * 8);
     const bool vec4 = (dim % 4 == 0) && (ld % 4 == 0) && (ldo % 4 == 0) && sage_aligned(table, 16) && sage_aligned(out, 16);
     if (vec4)

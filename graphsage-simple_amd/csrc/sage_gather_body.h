@@ -19,7 +19,7 @@ __device__ __forceinline__ void gather_sliced_block(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0, const int act = SAGE_ACT_NONE) {
     using V = __attribute__((ext_vector_type(4))) float;
     constexpr int NPI = kWave / SL;             // neighbours per wave-instruction
     // wave-instructions in flight: 8 neighbours per trip.  Deeper (4 x 4 neighbours) is no faster alone -- 32 waves per
@@ -84,6 +84,7 @@ __device__ __forceinline__ void gather_sliced_block(
             else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
             // streaming stores: the next kernel reads these rows from other XCDs anyway, and dirty lines left in L2 are
             // written back at the kernel boundary, on the critical path (gather 49.4 -> 48.3 us, contraction 22.2 -> 21.3)
+            if (act != SAGE_ACT_NONE) { res[0] = sage_activate(res[0], act); res[1] = sage_activate(res[1], act); res[2] = sage_activate(res[2], act); res[3] = sage_activate(res[3], act); }
             sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
         }
     }
@@ -104,7 +105,7 @@ __device__ __forceinline__ void gather_sliced_block_pipelined(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0, const int act = SAGE_ACT_NONE) {
     // R rows of the wave are in flight together (R x U wave-instructions): narrow slices (SL = 8: 128 B, one slice per
     // XCD, no hub row cached twice on the chip) put only 2 KiB of a row into one trip, too little to cover the fabric's
     // latency with the waves a shared CU can spare.
@@ -205,7 +206,8 @@ __device__ __forceinline__ void gather_sliced_block_pipelined(
                 V res;
                 if (ceff > 0) res = acc * (1.0f / (float)ceff);
                 else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
-                sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
+                if (act != SAGE_ACT_NONE) { res[0] = sage_activate(res[0], act); res[1] = sage_activate(res[1], act); res[2] = sage_activate(res[2], act); res[3] = sage_activate(res[3], act); }
+            sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
             }
         }
         r0 = rn0;
@@ -230,7 +232,7 @@ __device__ __forceinline__ void gather_sliced_block_rows(
     const float* __restrict__ table, int table_rows, int64_t ld, int dim,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt, int k, int n, const int32_t* __restrict__ n_dev,
     const int32_t* __restrict__ slot_rows, const int32_t* __restrict__ self_row, const int32_t* __restrict__ any_nonempty,
-    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0) {
+    float* __restrict__ out, int64_t ldo, int n_off, int nslice, const int bid, const int nblk, const int64_t slice_stride = 0, const int act = SAGE_ACT_NONE) {
     using V = __attribute__((ext_vector_type(4))) float;
     constexpr int NG = kWave / SL;              // destination rows per wave-instruction
     int nn = n;
@@ -294,6 +296,7 @@ __device__ __forceinline__ void gather_sliced_block_rows(
             V res;
             if (ceff > 0) res = acc * (1.0f / (float)ceff);
             else { const float fill = nan_rule ? __builtin_nanf("") : 0.f; res = V{fill, fill, fill, fill}; }
+            if (act != SAGE_ACT_NONE) { res[0] = sage_activate(res[0], act); res[1] = sage_activate(res[1], act); res[2] = sage_activate(res[2], act); res[3] = sage_activate(res[3], act); }
             sage_store_stream<SAGE_AGG_STORE>(reinterpret_cast<V*>(out + (int64_t)r * ldo + c0), res);
         }
     }

@@ -40,7 +40,7 @@ int sage_launch_sample_fused(const sage_model_t* m, const int32_t* seeds, int32_
 int sage_launch_gather_mean(const float* table, int64_t table_rows, int64_t ld, int32_t dim, const int32_t* nbr,
                             const int32_t* cnt, int32_t k, int32_t n, const int32_t* n_dev, const int32_t* slot_rows,
                             const int32_t* self_row, const int32_t* any_nonempty, float* out, int64_t ldo, int32_t n_off,
-                            hipStream_t st, int64_t slice_stride = 0);
+                            hipStream_t st, int64_t slice_stride = 0, int act = SAGE_ACT_NONE /* column-sliced forms only */);
 bool sage_layer_dense_supported(int32_t dim, int32_t out_dim);
 bool sage_gather_is_sliced(int32_t dim, int64_t ld, int64_t ldo, const float* table, const float* out, int32_t n, int32_t k);
 

@@ -21,7 +21,9 @@ def pretransform_table(table, w1, rows_per_call=1 << 18):
         y, eye = pretransform_table(table, w1)                       # [N, H1] fp32 on the table's device, identity [H1, H1]
         eng = TwoHopEngine(rowptr, col, y, eye, w2, k1, k2)          # or RolePipeline(rowptr, col, y, eye, w2, ...)
 
-    The engine is used UNCHANGED: with W1 := I the split-bf16 contraction returns its operand exactly (x = hi + mid + lo times 1.0).
+    The engine is used UNCHANGED: with W1 := I the split-bf16 contraction returns its operand exactly (x = hi + mid + lo times 1.0); and
+    since the returned identity is MARKED as such, the split layer skips that contraction altogether (the gather applies the activation
+    and writes h1) -- the same bits, one launch and one round trip of the means less.
     Same sampled sets as the plain engine for the same keys; values equal to a few fp32 roundings (the sums are associated
     differently: mean of products instead of product of the mean) -- inside the 1e-5 parity bar, not bit-identical.  Differences by
     construction: non-finite FEATURES meet W1 before the mean (Inf - Inf cases of torch.mm land elsewhere); training needs the plain
@@ -37,7 +39,9 @@ def pretransform_table(table, w1, rows_per_call=1 << 18):
     for lo in range(0, n, rows_per_call):
         hi = min(n, lo + rows_per_call)
         ops.linear_act(table[lo:hi], w, act=ops.ACT_NONE, out=y[lo:hi])
-    return y, torch.eye(h1, dtype=torch.float32, device=table.device)
+    eye = torch.eye(h1, dtype=torch.float32, device=table.device)
+    eye._sage_identity = True          # TwoHopEngine then declares it to the library (sage_model_t.w1_is_identity): layer 1's contraction is
+    return y, eye                      # skipped and the column-sliced gather applies the activation and writes h1 itself
 
 
 class TwoHopEngine:
@@ -253,6 +257,7 @@ class TwoHopEngine:
         self._model_c.seed_map = self._new_of_old.data_ptr() if self._new_of_old is not None else None
         self._model_c.table_sliced = self._table_sliced.data_ptr() if self._table_sliced is not None else None
         self._model_c.table_slice_floats = getattr(self, "_slice_floats", 64)
+        self._model_c.w1_is_identity = 1 if (getattr(self.w1, "_sage_identity", False) and not self.concat and not self._padded) else 0
         self._model_q = None
         if self._queue is not None:
             self._model_q = native.Model.from_buffer_copy(self._model_c)
@@ -384,6 +389,9 @@ class TwoHopEngine:
         workspace, the layer-2 means are re-gathered -- with the C-ABI backward kernels.  The table is frozen (model.py:214-215):
         no gradient reaches it.  No host synchronisation: the frontier size never leaves the device."""
         from . import ops
+        if getattr(self.w1, "_sage_identity", False):
+            raise native.SageError("backward_weights: this engine serves a PRE-TRANSFORMED table (W1 is a declared identity): train with the "
+                                   "plain engine on the raw features")
         lib = native.lib()
         st = native.stream_handle()
         P = native.ptr

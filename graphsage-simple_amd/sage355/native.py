@@ -51,7 +51,7 @@ class Model(Structure):
                 ("k1", c_int32), ("k2", c_int32), ("concat", c_int32), ("agg_self_loop", c_int32),
                 ("act1", c_int32), ("act2", c_int32), ("nan_empty", c_int32), ("fused", c_int32), ("ws_batch", c_int32),
                 ("queue", c_void_p), ("queue_len", c_int32), ("queue_cursor", c_void_p), ("w1_prepared", c_void_p), ("seed_map", c_void_p),
-                ("table_sliced", c_void_p), ("table_slice_floats", c_int32)]
+                ("table_sliced", c_void_p), ("table_slice_floats", c_int32), ("w1_is_identity", c_int32)]
 
 
 class Batch(Structure):      # sage_batch_t, lives in device memory (16 bytes)

@@ -303,6 +303,12 @@ typedef struct {
      * column-sliced layer-1 gather then reads one contiguous array per 256-byte slice.  NULL = gather from `table`. */
     const float*   table_sliced;
     int32_t        table_slice_floats;  /* floats per slice of table_sliced: 64 (256-byte slices; 0 means 64) or 32 / 128; d0 % it == 0 */
+    /* optional (ABI 4): the caller DECLARES that w1 is the identity matrix [h1, h1] (d0 == h1, gcn encoder) -- serving on a pre-transformed
+     * table, Y = X . W1^T computed once per weight update (sage355.engine.pretransform_table): layer 1 is then act1(mean(Y[nbrs])).  When
+     * layer 1 runs in its split form the contraction is skipped and the column-sliced gather applies act1 and writes h1 itself; everywhere
+     * else the flag is ignored (the contraction with an identity W1 returns its operand exactly, so the result is the same bit for bit).
+     * w1 must still point at a real identity matrix. */
+    int32_t        w1_is_identity;
 } sage_model_t;
 
 /* Where the intermediates of one forward live inside the caller's workspace

@@ -632,6 +632,13 @@ def test_pretransformed_table_inference_matches_the_oracle(relabel, self_loop):
     ref_y = (table.double() @ w1.double().t())
     assert ((y.cpu().double() - ref_y).abs().max() / ref_y.abs().max()).item() < 1e-6          # the library's fp32-accurate contraction
     pre = TwoHopEngine(rowptr, col, y, eye, w2d, k1, k2, max_batch=b, relabel=relabel, agg_self_loop=self_loop)
+    assert pre._model().w1_is_identity == 1                    # the marked identity: layer 1 = gather + activation, no contraction launch
+    # an UNMARKED identity matrix goes through the contraction (x . 1.0 from the three bf16 terms of x is x): the same bits
+    unmarked = TwoHopEngine(rowptr, col, y, torch.eye(128, device=DEV), w2d, k1, k2, max_batch=b, relabel=relabel, agg_self_loop=self_loop)
+    assert unmarked._model().w1_is_identity == 0
+    assert torch.equal(pre.forward(seeds, seed=77), unmarked.forward(seeds, seed=77))
+    with pytest.raises(native_mod.SageError, match="PRE-TRANSFORMED"):
+        pre.backward_weights(torch.zeros(b, 64, device=DEV), torch.zeros(b, 64, device=DEV))
     a = plain.forward(seeds, seed=77).clone()
     ia = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in plain.intermediates().items()}
     c = pre.forward(seeds, seed=77).clone()
