@@ -451,7 +451,9 @@ def main():
     #      (a) IN SITU: the same K steps again in the same execution mode (the pipeline running, events around the gather on
     #          stream G) -- what the timed region's kernel launches took, overlap stretch included;
     #      (b) ALONE: host-enqueued forwards, one batch in flight -- the kernel's own speed.
-    #      Both are RAW event intervals (an upper bound of the kernel's duration: they include the event packets).
+    #      Both intervals are between the gather launch's OWN start / stop events (hipExtLaunchKernelGGL; csrc/sage_gather.hip's measurement
+    #      hook), i.e. the kernel's execution as rocprofv3 reports it -- until round 3 they were marker packets around the launch, which in
+    #      a busy queue read 5-9 us longer.  The other stages' figures in stage_ms_alone are still marker intervals.
     #      The data-determined set sizes of every batch are counted by torch reductions after pass (b). ----
     roofline = None
     if rank == 0:
@@ -555,9 +557,9 @@ def main():
                           "the [|S1|, D0] means (a round trip the split layer adds) is excluded here and included in bytes_per_launch_own",
             "bytes_per_launch_own": round(own),
             "kernel_ms": round(kernel_ms, 5),
-            "kernel_ms_is": ("raw HIP-event interval around the launch on its own stream, measured in the running role pipeline "
-                             "(overlap with the other stages' kernels included)" if insitu_ms is not None else
-                             "raw HIP-event interval around the launch on its own stream, one batch in flight"),
+            "kernel_ms_is": ("the launch's own start / stop HIP events (hipExtLaunchKernelGGL on the kernel's stream), measured in the running "
+                             "role pipeline (overlap with the other stages' kernels included)" if insitu_ms is not None else
+                             "the launch's own start / stop HIP events, one batch in flight"),
             "kernel_ms_alone": round(alone_ms, 5), "frac_alone": round(l1 / (alone_ms * 1e-3) / HBM_PEAK, 4),
             # the basis of round 1's figure (kernel alone, its own bytes incl. the write of the means): 0.388 there
             "frac_alone_own_bytes": round(own / (alone_ms * 1e-3) / HBM_PEAK, 4),

@@ -184,7 +184,11 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                               sage_gather_is_sliced(m->d0, m->table_ld, m->h1, m->table, h1, L.max_s1, m->k1);
     // 3. layer 1 on S1: the HBM-bound gather ...
     if (stages & SAGE_STAGE_GATHER1) {
-    SAGE_EV(4);
+    // (sage_forward2_profiled: events 4 / 5 are the gather launch's own start / stop events when it takes a column-sliced form)
+    const sage_ext_launch_t gx{ev ? ev[4] : nullptr, ev ? ev[5] : nullptr};
+    const bool ext_g = ev && ev[4] && ev[5] && (gather_only1 || split1) && sage_ext_launch == nullptr;
+    if (ext_g) sage_ext_launch = &gx; else SAGE_EV(4);
+    struct ClearHook { bool on; ~ClearHook() { if (on) sage_ext_launch = nullptr; } } clear_hook{ext_g};
     if (gather_only1) {
         const int sw = m->table_slice_floats ? m->table_slice_floats : 64;
         const bool sm = m->table_sliced != nullptr && (sw == 32 || sw == 64 || sw == 128) && m->d0 % sw == 0 && sage_aligned(m->table_sliced, 16);
@@ -201,7 +205,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                              sm ? m->num_nodes * (int64_t)sw : 0))
             return rc;
     }
-    SAGE_EV(5);
+    if (!ext_g) SAGE_EV(5);
     }
     // ... and its contraction (one launch with the gather unless the layer is split); then layer 2.  The 512-deep concat layer is two
     // launches (sage_dense.hip): the nodes' own rows' chunk -- which needs the sampling only, so the role pipeline asks for it alone

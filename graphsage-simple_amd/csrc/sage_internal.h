@@ -65,6 +65,10 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
 #define SAGE_DENSE_PART_ALL  3
 bool sage_layer_dense_two_launches(int32_t dim, int32_t out_dim, int32_t concat, const void* weight_prepared, const float* out, int64_t ldo);
 
+// Measurement hook (sage_gather.hip): set by the thread that is about to launch the layer-1 gather, cleared right after.
+struct sage_ext_launch_t { void* start; void* stop; };
+extern thread_local const sage_ext_launch_t* sage_ext_launch;
+
 // The launches of one forward, by stage (sage_pipe.hip enqueues each stage on its role stream)
 #define SAGE_STAGE_SAMPLE_OUTER 1
 #define SAGE_STAGE_SAMPLE_INNER 2
