@@ -12,5 +12,7 @@ import os as _os
 # RolePipeline runs the stages of consecutive forwards on four HIP streams.  ROCm gives a process 4 hardware queues by
 # default and maps all HIP streams onto them round-robin; two role streams on one queue serialise (measured on MI355X:
 # 82.6 us per forward with 4 queues, 69.1 us with 6 or more).  The HIP runtime reads this when it initialises, so it is set
-# here, at import time, unless the user has chosen a value.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# here, at import time, unless the user has chosen a value -- or does not want a library to touch the process environment at all
+# (SAGE355_KEEP_ENV=1: then give the process GPU_MAX_HW_QUEUES >= 6 yourself if you use RolePipeline).
+if _os.environ.get("SAGE355_KEEP_ENV", "0") != "1":
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

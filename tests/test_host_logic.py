@@ -222,3 +222,16 @@ def test_classifier_gradient_is_summed_over_the_batch_in_a_fixed_order():
         if b % 256 == 0 and b > 256:
             want = sum((g[i:i + 256].t() @ e[i:i + 256]).double() for i in range(0, b, 256))
             assert (got.double() - want).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_import_leaves_the_environment_alone_when_asked(tmp_path):
+    """`import sage355` defaults GPU_MAX_HW_QUEUES=8 (role streams need a hardware queue each) unless the user chose a value or set
+    SAGE355_KEEP_ENV=1 (a side effect a host application may not expect)."""
+    import os, subprocess, sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graphsage-simple_amd")
+    code = "import os, sys; sys.path.insert(0, %r); import sage355; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % pkg
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SAGE355_KEEP_ENV")}
+    run = lambda env: subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip()
+    assert run(base) == "8"
+    assert run(dict(base, GPU_MAX_HW_QUEUES="5")) == "5"
+    assert run(dict(base, SAGE355_KEEP_ENV="1")) == "None"
