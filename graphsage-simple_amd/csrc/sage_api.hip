@@ -37,7 +37,10 @@ const sage_tunables_t& sage_tunables() {
         x.gather_trip = env_int("SAGE_G_TRIP", 16, 8, 16) >= 16 ? 16 : 8;
         x.gather_variant = env_int("SAGE_G_VARIANT", 1, 0, 2);
         x.gather_variant_sliced = env_int("SAGE_G_VARIANT_SM", getenv("SAGE_G_VARIANT") ? x.gather_variant : 2, 0, 2);
-        x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", kNumCU, 32, 512);
+        // 224 since the end of round 3 (256 before): the concat encoder's pipeline, whose pacemaker the contraction is, gains 4-5 % (config 3:
+        // 88.9 -> 84.5 us per forward, config 5: 84.5 -> 81.5; three / two interleaved runs, experiments/r03/call61.sh), the gcn one is
+        // indifferent (58.4 vs 58.4); alone the kernel loses ~1 us (four tile rounds instead of three)
+        x.dense_blocks = env_int("SAGE_DENSE_BLOCKS", 224, 32, 512);
         x.bwd_blocks = env_int("SAGE_BWD_BLOCKS", 512, 16, 4096);
         x.bwd_direct_blocks = env_int("SAGE_BWD_DIRECT_BLOCKS", 256, 16, 1024);
         // 512 since round 3: once the slice-major table took the gather off the critical path the sampler stream showed up --

@@ -92,7 +92,7 @@ struct sage_tunables_t {
     int gather_trip;              // SAGE_G_TRIP          rows form: neighbours of a row requested per trip (8 / 16), default 16
     int gather_variant;           // SAGE_G_VARIANT       0 = three-trip rows, 1 = rows software-pipelined (default), 2 = one row per lane group
     int gather_variant_sliced;    // SAGE_G_VARIANT_SM    the variant used with a slice-major table (sage_model_t.table_sliced): 2 (default) / 1 / 0
-    int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 256
+    int dense_blocks;             // SAGE_DENSE_BLOCKS    split-bf16 contraction: persistent 512-thread blocks (32..512), default 224
     int bwd_blocks;               // SAGE_BWD_BLOCKS      weight-gradient GEMM: blocks over (tiles x K splits), default 2 per CU (every split adds its tile with fp32 atomics)
     int bwd_direct_blocks;        // SAGE_BWD_DIRECT_BLOCKS  reproducible weight gradient: row ranges = 512-thread blocks = partial tiles (16..1024), default 256
     int outer_threads;            // SAGE_SO_THREADS      outer-hop sampler block size (256 / 512 / 1024), default 512 (1024 until round 3)
