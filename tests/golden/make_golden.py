@@ -30,11 +30,13 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, REF)   # the reference's `graphsage` must win over this repo's drop-in shim
 sys.path.insert(1, os.path.join(REPO, "graphsage-simple_amd"))
+sys.path.insert(2, os.path.join(REPO, "tests"))
 warnings.filterwarnings("ignore")
 
 from graphsage.aggregators import MeanAggregator  # noqa: E402  (the reference)
 from graphsage.encoders import Encoder            # noqa: E402  (the reference)
 from sage355 import graph as G                    # noqa: E402  (host-only ingestion)
+from util import TABLE_KINDS, synth_table         # noqa: E402  (tests/util.py: the batch-size fixtures' table generator)
 
 
 def quiet(fn, *a, **k):
@@ -83,7 +85,9 @@ def build_reference_stack(table, sets1, sets2, w1, w2, gcn, init1="None", init2=
     return features, agg1, enc1, agg2, enc2
 
 
-def two_layer_case(name, graph, table, seeds, k1, k2, h1, h2, gcn, seed, init1="None", init2="None"):
+def two_layer_case(name, graph, table, seeds, k1, k2, h1, h2, gcn, seed, init1="None", init2="None", table_spec=None):
+    """table_spec = (kind code, generator seed): a BATCH-SIZE fixture -- `table` came from tests/util.synth_table(kind, N, D0, seed) and
+    is NOT stored (its sha256 is; the tests regenerate it), and of the [|S1|, D0] layer-1 aggregator output only 16 rows are."""
     rng = random.Random(seed)
     gen = torch.Generator().manual_seed(seed)
     adj = graph.to_adj_lists()
@@ -109,18 +113,24 @@ def two_layer_case(name, graph, table, seeds, k1, k2, h1, h2, gcn, seed, init1="
     nbr2, cnt2 = pad_sets(seeds, sets2, k2)
     nbr1, cnt1 = pad_sets(layer1_nodes, sets1, k1)
     touched = sorted(set(layer1_nodes) | set(int(x) for x in nbr1[nbr1 >= 0]))
-    np.savez_compressed(
-        os.path.join(HERE, name + ".npz"),
+    common = dict(
         num_nodes=np.int64(table.shape[0]), d0=np.int64(d0), k1=np.int64(k1), k2=np.int64(k2),
         gcn=np.int64(gcn), sigmoid1=np.int64(init1 in ("node_degree", "shared", "pagerank")),
         sigmoid2=np.int64(init2 in ("node_degree", "shared", "pagerank")),
         seeds=np.array(seeds, dtype=np.int64), nbr2=nbr2, cnt2=cnt2,
         layer1_nodes=np.array(layer1_nodes, dtype=np.int64), nbr1=nbr1, cnt1=cnt1,
-        feat_ids=np.array(touched, dtype=np.int64), feat_rows=table[touched].numpy(),
-        w1=w1.numpy(), w2=w2.numpy(),
-        agg1_out=agg1_out.numpy(), enc1_out=enc1_out.numpy(),
-        agg2_out=agg2_out.numpy(), enc2_out=enc2_out.numpy(),
+        w1=w1.numpy(), w2=w2.numpy(), enc1_out=enc1_out.numpy(), agg2_out=agg2_out.numpy(), enc2_out=enc2_out.numpy(),
         cotangent=cot.numpy(), grad_w1=enc1.weight.grad.numpy(), grad_w2=enc2.weight.grad.numpy())
+    if table_spec is None:
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), feat_ids=np.array(touched, dtype=np.int64), feat_rows=table[touched].numpy(),
+                            agg1_out=agg1_out.numpy(), **common)
+    else:
+        import hashlib
+        kind, tseed = table_spec
+        rows = np.sort(np.random.default_rng(seed).choice(len(layer1_nodes), min(16, len(layer1_nodes)), replace=False)).astype(np.int64)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), table_kind=np.int64(kind), table_seed=np.int64(tseed),
+                            table_sha256=np.frombuffer(hashlib.sha256(table.numpy().tobytes()).digest(), dtype=np.uint8),
+                            agg1_rows=rows, agg1_out_rows=agg1_out.numpy()[rows], **common)
     print(f"{name}: B={len(seeds)} |S1|={len(layer1_nodes)} E1={int(cnt1.sum())} touched={len(touched)} "
           f"enc2_out {tuple(enc2_out.shape)} max|out|={float(enc2_out.abs().max()):.4f}")
 
@@ -312,7 +322,29 @@ def reference_f1_fixture_pubmed(g_pub):
                                                                          fixture["f1_macro_mean"], fixture["f1_macro_std"]))
 
 
+def batch_size_cases(g_cora, g_pub):
+    """BASELINE configs[0] / configs[1] at their batch size: B = 256 seeds, Cora 1433 -> 50 -> 128 with the fanout the
+    reference really runs (10 / 10: model.py:223-224 writes `num_samples`, encoders.py:23 reads `num_sample`) and the 5 / 5 the config
+    names; Pubmed 500 -> 50 -> 128, fanout 10 / 25; both encoder modes.  Generators of their own: the small cases' streams stay as they were."""
+    inv = {v: k for k, v in TABLE_KINDS.items()}
+    bow = torch.from_numpy(synth_table("bow", 2708, 1433, 20241))
+    for i, (k1, k2, gcn) in enumerate([(10, 10, True), (10, 10, False), (5, 5, True), (5, 5, False)]):
+        seeds = np.random.default_rng(100 + i).choice(2708, 256, replace=False)
+        two_layer_case(f"cora_{'gcn' if gcn else 'concat'}_{k1}_{k2}_b256", g_cora, bow, seeds, k1, k2, 50, 128, gcn, 20 + i,
+                       table_spec=(inv["bow"], 20241))
+    tfidf = torch.from_numpy(synth_table("tfidf", 19717, 500, 20242))
+    for i, gcn in enumerate([True, False]):
+        seeds = np.random.default_rng(200 + i).choice(19717, 256, replace=False)
+        two_layer_case(f"pubmed_{'gcn' if gcn else 'concat'}_10_25_b256", g_pub, tfidf, seeds, 10, 25, 50, 128, gcn, 30 + i,
+                       table_spec=(inv["tfidf"], 20242))
+
+
 def main():
+    if "--b256-only" in sys.argv:
+        g_cora, _ = G.read_edge_list(os.path.join(REF, "cora/cora.cites"))
+        g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")
+        batch_size_cases(g_cora, g_pub)
+        return
     if "--f1-pubmed-only" in sys.argv:
         g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")
         reference_f1_fixture_pubmed(g_pub)
@@ -348,6 +380,7 @@ def main():
     two_layer_case("pubmed_concat_10_25", g_pub, tfidf, rs.choice(19717, 4, replace=False), 10, 25, 50, 128, False, 9)
     if "--f1" in sys.argv or not os.path.exists(os.path.join(HERE, "reference_f1_pubmed_standin.json")):
         reference_f1_fixture_pubmed(g_pub)
+    batch_size_cases(g_cora, g_pub)
 
 
 if __name__ == "__main__":

@@ -5,8 +5,13 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TWO_LAYER_CASES = ["tiny_gcn", "tiny_concat", "tiny_sigmoid", "cora_emb_gcn_5_5", "cora_emb_concat_10_10",
-                   "cora_bow_gcn_5_5", "cora_bow_concat_5_5", "pubmed_gcn_10_25", "pubmed_concat_10_25"]
+# *_b256: BASELINE configs[0] / configs[1] at their batch size (B = 256 seeds, full feature widths), the reference's own outputs
+# (round 4; the table of such a fixture is regenerated from a committed integer seed, see synth_table / full_table)
+TWO_LAYER_CASES_SMALL = ["tiny_gcn", "tiny_concat", "tiny_sigmoid", "cora_emb_gcn_5_5", "cora_emb_concat_10_10",
+                         "cora_bow_gcn_5_5", "cora_bow_concat_5_5", "pubmed_gcn_10_25", "pubmed_concat_10_25"]
+TWO_LAYER_CASES_B256 = ["cora_gcn_10_10_b256", "cora_concat_10_10_b256", "cora_gcn_5_5_b256", "cora_concat_5_5_b256",
+                        "pubmed_gcn_10_25_b256", "pubmed_concat_10_25_b256"]
+TWO_LAYER_CASES = TWO_LAYER_CASES_SMALL + TWO_LAYER_CASES_B256
 
 # BASELINE.json north_star: "within 1e-5 relative fp32".  SURVEY.md section 7 (Tolerance
 # definition): the reference's own fp32 result is only reproducible relative to the row
@@ -19,11 +24,42 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
+TABLE_KINDS = {0: "bow", 1: "tfidf"}
+
+
+def synth_table(kind, n, d, seed):
+    """Feature tables of the batch-size fixtures, a pure function of (kind, n, d, seed) -- shared with tests/golden/make_golden.py, which
+    records the sha256 of the bytes it fed to the reference.  bow: Cora-like 0/1 bag of words (18 words of 1433 per paper on average);
+    tfidf: SURVEY 8(d)'s Pubmed stand-in, rand * Bernoulli(0.1)."""
+    rng = np.random.default_rng(int(seed))
+    if kind == "bow":
+        return (rng.random((n, d)) < 18.0 / d).astype(np.float32)
+    if kind == "tfidf":
+        return (rng.random((n, d)) * (rng.random((n, d)) < 0.1)).astype(np.float32)
+    raise ValueError(kind)
+
+
 def full_table(g):
-    """Rebuild the [N, D0] table: only the touched rows are stored in a fixture."""
+    """Rebuild the [N, D0] table: a small fixture stores the touched rows, a batch-size fixture the generator's (kind, seed) and
+    the checksum of the table the reference saw."""
+    if "table_kind" in g:
+        import hashlib
+        t = synth_table(TABLE_KINDS[int(g["table_kind"])], int(g["num_nodes"]), int(g["d0"]), int(g["table_seed"]))
+        digest = np.frombuffer(hashlib.sha256(t.tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(digest, g["table_sha256"]), "regenerated feature table differs from the one the reference was run on"
+        return torch.from_numpy(t)
     t = torch.zeros(int(g["num_nodes"]), int(g["d0"]))
     t[torch.from_numpy(g["feat_ids"])] = torch.from_numpy(g["feat_rows"])
     return t
+
+
+def assert_agg1_close(actual, g, what="agg1_out"):
+    """Layer-1 aggregator output against the fixture: all rows (small fixtures), or the recorded sample of rows (batch-size
+    fixtures keep 16 of the [|S1|, D0] rows: the whole matrix is 7 MB at Cora's width)."""
+    if "agg1_out" in g:
+        return assert_close_rowmax(actual, g["agg1_out"], what=what)
+    rows = torch.from_numpy(g["agg1_rows"])
+    return assert_close_rowmax(torch.as_tensor(np.asarray(actual))[rows], g["agg1_out_rows"], what=what + " (row sample)")
 
 
 def sets_from_padded(nodes, nbr, cnt):
