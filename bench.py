@@ -102,9 +102,10 @@ def parse():
                     help="BASELINE.json configs[] preset: 3 = the bench line (default); 2 = Pubmed topology D0=500 H=50/128 fanout 10/25 "
                          "B=256; 4 = R-MAT 2^23 / 128 M edges; 5 = ogbn-products-shaped 2.4 M nodes / 62 M edges D0=100 fanout 20/25")
     ap.add_argument("--scale-variant", choices=["auto", "on", "off"], default=os.environ.get("SAGE_SCALE_VARIANT", "auto"),
-                    help="N > 1 (auto) or always (on): after the headline run, time the same K steps on BASELINE configs[3] (R-MAT 2^23 / "
-                         "128 M edges, the workload BASELINE names for the 1/2/4/8 scaling curve) and report it as "
-                         "config.variants.configs3_rmat23; `value` stays on configs[2]")
+                    help="auto (default): with the headline on configs[2], ALSO run BASELINE configs[3] (R-MAT 2^23 / 128 M edges, the workload "
+                         "BASELINE names for the 1/2/4/8 scaling curve) through the same measurement code at every N and report it as "
+                         "config.variants.configs3_rmat23 (own parity gate, timed-path check, counted bytes, live kernel timing); `value` stays "
+                         "on configs[2].  on: whatever --config is; off: never")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsing N > 1 on a 1-GPU box)")
@@ -221,9 +222,97 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from sage355 import native
+    native.lib()
+    host = host_plan(args, world)
+
+    def fence(p=None):
+        if p is not None:
+            p.flush()                             # host enqueue threads: everything submitted is on the streams
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the headline: BASELINE configs[2] (or --config N) ----
+    head = run_workload(args, rank, world, dev, dist, fence, host, side_variants=not args.no_variant, with_cpu=args.cpu_seconds > 0)
+    variants = head.pop("variants", None) if head is not None else None
+
+    # ---- BASELINE configs[3] (R-MAT 2^23 / 128 M edges: the workload BASELINE names for the 1/2/4/8 curve) beside it, at EVERY N since round 4
+    #      (VERDICT r3 #2): the same function, hence the same K / W, fences, max-over-ranks, oracle gate, timed-path check, counted bytes and
+    #      live kernel timing as the headline; never substituted for `value` ----
+    if args.scale_variant == "on" or (args.scale_variant == "auto" and args.config == 3):
+        import copy
+        a4 = copy.copy(args)
+        for key, val in PRESETS[4].items():
+            setattr(a4, key, val)
+        a4.config, a4.truncate = 4, 0
+        torch.cuda.empty_cache()
+        sv = run_workload(a4, rank, world, dev, dist, fence, host, side_variants=False, with_cpu=False)
+        if rank == 0:
+            ro = sv["roofline"] or {}
+            variants = dict(variants or {}, configs3_rmat23={
+                "value": sv["value"], "unit": "embeddings/s", "ms_per_step": sv["ms_per_step"], "n_gpus": world, "workload": sv["workload"],
+                "execution": sv["execution"], "parity_max_err_vs_fp64_oracle": sv["parity_err"], "timed_path_check": sv["timed_check"],
+                "forward_bytes": ro.get("forward_bytes"), "forward_GBps": ro.get("forward_GBps"), "forward_frac": ro.get("forward_frac"),
+                "roofline": {k: ro.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "kernel_ms", "kernel_ms_is",
+                                                     "kernel_ms_alone", "frac_alone", "stage_ms_alone", "mean_sizes", "per_edge_gather_bytes")},
+                "setup_seconds": sv["setup_seconds"],
+                "note": "the workload BASELINE names for the 1/2/4/8 curve, measured by the same code path as the headline (steps / warm-up / "
+                        "fences / max-over-ranks / oracle gate on the last timed batch / bit-for-bit check of the timed path's output / bytes "
+                        "counted per batch / the gather launch's own start-stop events); `value` stays on configs[2]"})
+
+    if rank == 0:
+        line = {
+            "metric": "node-embeddings/sec (2-hop forward)", "value": head["value"], "unit": "embeddings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": dict(head["config"], variants=variants, host=host,
+                           parallelism=f"seed-shard x{world}, replicated graph+features, no forward collective"),
+            "parity_max_err_vs_fp64_oracle": head["parity_err"], "timed_path_check": head["timed_check"],
+            "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"],
+        }
+        print(json.dumps(line), flush=True)
+        if os.environ.get("SAGE_BENCH_RESULT_FILE"):          # the self-launching parent reads it from here (see self_launch)
+            with open(os.environ["SAGE_BENCH_RESULT_FILE"], "w") as fh:
+                fh.write(json.dumps(line) + "\n")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def usable_host_cores():
+    """Host cores this process may actually use: the affinity mask / cgroup quota, not the machine's core count."""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return usable
+
+
+def host_plan(args, world):
+    """How the role pipeline is fed.  One host enqueue thread per role stream (four spinning threads + the submitter
+    per rank) only where every rank of this node has at least five usable cores to itself; otherwise the submitting thread makes all
+    of a batch's HIP calls itself.  Reported in config.host of every line."""
+    usable = usable_host_cores()
+    per_rank = usable // max(1, world)
+    want = bool(args.host_threads) and len(set(args.roles)) == 4
+    threads = want and per_rank >= 5
+    return {"host_cores_usable": usable, "ranks_on_node": world, "cores_per_rank": per_rank,
+            "enqueue_mode": "one host thread per role stream" if threads else "submitting thread only",
+            "why": ("--host-threads 0 / fewer than four role streams" if not want else
+                    "cores_per_rank >= 5" if threads else "cores_per_rank < 5: five busy host threads per rank would oversubscribe the node"),
+            "role_threads": bool(threads)}
+
+
+def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_cpu):
+    """One workload (args.config and the sizes its preset filled in) through the parity gate, the timed region, the timed-path check and
+    the kernel / byte accounting.  Every rank runs it; rank 0 returns the dict the JSON line is made of, the others None."""
+    t_setup = time.perf_counter()
     from sage355.engine import RolePipeline, TwoHopEngine
     from sage355.graph import rmat_graph
-    native.lib()
 
     # ---- synthetic inputs (SURVEY.md 8d): rank 0 generates, the others load its cache ----
     def make_graph():
@@ -312,7 +401,7 @@ def main():
     if exec_mode in ("pipe", "pipegraph"):
         pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles,
                             priorities={ch: -1 for ch in args.high_priority},
-                            threads=bool(args.host_threads) and exec_mode == "pipe" and len(set(args.roles)) == 4, window=args.window, **ekw)
+                            threads=host["role_threads"] and exec_mode == "pipe", window=args.window, **ekw)
         pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
         torch.cuda.synchronize()
         if exec_mode == "pipegraph":
@@ -372,14 +461,7 @@ def main():
                 else:
                     engines[s].forward(seeds_dev[i], seed=sampler_seed[i], out=outs[s])
 
-    def fence(p=None):
-        if p is not None:
-            p.flush()                             # host enqueue threads: everything submitted is on the streams
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    setup_seconds = time.perf_counter() - t_setup
     # ---- preheat (untimed, throw-away batches, same execution mode), then W warm-up steps, then the timed region ----
     preheat_forwards = 0
     if args.preheat_seconds > 0:
@@ -596,7 +678,7 @@ def main():
     # ---- variant, reported beside the headline and never substituted for it: the same K steps with the engine keeping the
     #      CALLER's node order (no degree-sorted internal layout), same execution mode ----
     variants = None
-    if rank == 0 and world == 1 and pipe is not None and relabel is not None and not args.no_variant:
+    if rank == 0 and world == 1 and pipe is not None and relabel is not None and side_variants:
         role_streams = pipe.distinct_streams()       # the variant runs on the SAME role streams (hence hardware queues)
         pipe_threads = pipe.threads
         del pipe
@@ -667,20 +749,10 @@ def main():
     else:
         was_pipe = pipe is not None
 
-    # ---- BASELINE configs[3] as a variant of every N > 1 line: the scaling curve's own workload, same K / W, same
-    #      fences and max-over-ranks; never substituted for `value` ----
-    if args.scale_variant == "on" or (args.scale_variant == "auto" and world > 1 and args.config == 3):
-        pipe = None
-        base = None
-        engines, outs = [], []
-        torch.cuda.empty_cache()
-        sv = scaling_variant(args, rank, world, dev, dist, fence)
-        if rank == 0:
-            variants = dict(variants or {}, configs3_rmat23=sv)
-
+    result = None
     # ---- CPU side by side: the reference-faithful restatement on this box's host cores ----
     cpu_baseline = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and with_cpu:
         cpu_baseline = cpu_port_baseline(graph, table.cpu(), w1.cpu(), w2.cpu(), candidates, k1, k2, concat, args.cpu_seconds)
 
     if rank == 0:
@@ -694,10 +766,10 @@ def main():
             execution = f"hipGraph replay from a device batch queue, {nstreams} forwards in flight"
         else:
             execution = f"host-enqueued sage_forward2, {nstreams} forwards in flight"
-        line = {
-            "metric": "node-embeddings/sec (2-hop forward)", "value": round(value, 1), "unit": "embeddings/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        result = {
+            "value": round(value, 1), "ms_per_step": round(ms_per_step, 5), "workload": workload, "execution": execution,
+            "parity_err": parity_err, "timed_check": timed_check, "roofline": roofline, "cpu_baseline": cpu_baseline, "variants": variants,
+            "setup_seconds": round(setup_seconds, 1),
             "config": {"workload": workload,
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
                        "execution": execution, "host_enqueue_ms_per_step": round(host_enqueue_ms, 5),
@@ -711,80 +783,14 @@ def main():
                                         os.environ.get("SAGE_TABLE_SLICED", "1") != "0" and bool(base_split)) else "row-major"),
                        "contraction": "bf16x3-split MFMA (fp32-accurate: x.w from the three bf16 terms of x and of w; weight planes prepared "
                                       "once per weight update by sage_prepare_weights)",
-                       "batches_per_replay": bpr if exec_mode == "replay" else 1,
-                       "variants": variants,
-                       "parallelism": f"seed-shard x{world}, replicated graph+features, no forward collective"},
-            "parity_max_err_vs_fp64_oracle": parity_err, "timed_path_check": timed_check,
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+                       "batches_per_replay": bpr if exec_mode == "replay" else 1},
         }
-        print(json.dumps(line), flush=True)
-        if os.environ.get("SAGE_BENCH_RESULT_FILE"):          # the self-launching parent reads it from here (see self_launch)
-            with open(os.environ["SAGE_BENCH_RESULT_FILE"], "w") as fh:
-                fh.write(json.dumps(line) + "\n")
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def scaling_variant(args, rank, world, dev, dist, fence):
-    """K steps of the role pipeline on BASELINE configs[3] (R-MAT 2^23 nodes / 128 M edges, D0 = 256, H = 128/128, fanout 15/25,
-    B = 4096 seeds per GPU): replicated graph + table (8.6 GB + 1.1 GB per GPU), every rank its own seed batches, no forward
-    collective; warm-up, fences and max-over-ranks as the headline run.  -> dict for config.variants (rank 0) / None."""
-    from sage355.engine import RolePipeline
-    from sage355.graph import rmat_graph
-    P = PRESETS[4]
-    if rank == 0:
-        graph = rmat_graph(P["scale"], P["edges"], seed=0, cache_dir=CACHE_DIR)
-    if dist is not None:
-        dist.barrier()
-    if rank != 0:
-        graph = rmat_graph(P["scale"], P["edges"], seed=0, cache_dir=CACHE_DIR)
-    n, d0, h1, h2, k1, k2, b = graph.num_nodes, P["dim"], P["hidden1"], P["hidden"], P["k1"], P["k2"], P["batch"]
-    concat = args.mode == "concat"
-    mult = 2 if concat else 1
-    gen = torch.Generator(device=dev).manual_seed(0)
-    table = torch.randn(n, d0, generator=gen, device=dev)
-    wgen = torch.Generator().manual_seed(0)
-    w1 = ((torch.rand(h1, mult * d0, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h1 + mult * d0))).to(dev)
-    w2 = ((torch.rand(h2, mult * h1, generator=wgen) * 2 - 1) * np.sqrt(6.0 / (h2 + mult * h1))).to(dev)
-    rowptr, col = graph.to(dev)
-    candidates = np.nonzero(graph.degrees() > 0)[0]
-    total = args.warmup + args.steps
-    rs = np.random.default_rng(1 + 7919 * rank)
-    seeds = torch.from_numpy(np.stack([rs.choice(candidates, b, replace=False) for _ in range(total)]).astype(np.int32)).to(dev)
-    keys = [0x5A6E355 + 1000003 * rank + i for i in range(total)]
-    relabel = "degree" if args.engine_layout == "degree" else None
-    pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles, concat=concat,
-                        agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel,
-                        threads=bool(args.host_threads) and len(set(args.roles)) == 4, window=args.window)
-    out = torch.empty(max(args.depth, 4), b, h2, device=dev)
-    torch.cuda.synchronize()
-    t_ph = time.perf_counter()
-    while time.perf_counter() - t_ph < min(args.preheat_seconds, 0.3):
-        pipe.submit_many(seeds[:min(total, 8)], keys[:min(total, 8)], out)
-        pipe.flush()
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        pipe.submit(seeds[i], keys[i], out[i % out.shape[0]])
-    fence(pipe)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        pipe.submit(seeds[i], keys[i], out[i % out.shape[0]])
-    fence(pipe)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    del pipe
-    torch.cuda.synchronize()
-    if rank != 0:
-        return None
-    return {"value": round(world * b * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 5), "n_gpus": world,
-            "workload": f"BASELINE configs[3]: R-MAT 2^{P['scale']} / {P['edges']} edges ({n} nodes), {graph.nnz} directed nnz, {d0}-dim fp32 "
-                        f"features, {args.mode} encoder H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU, role pipeline depth {args.depth}",
-            "note": "the workload BASELINE names for the 1/2/4/8 curve; same steps / warm-up / fences / max-over-ranks as `value`, which "
-                    "stays on configs[2]"}
+    # this workload's device objects go before the next one is built (configs[3]: 8.6 GB table + its slice-major copy)
+    pipe = base = e = None
+    engines, outs = [], []
+    del table, rowptr, col, seeds_dev
+    torch.cuda.empty_cache()
+    return result
 
 
 def cpu_port_baseline(graph, table, w1, w2, candidates, k1, k2, concat, budget_s):
@@ -811,13 +817,7 @@ def cpu_port_baseline(graph, table, w1, w2, candidates, k1, k2, concat, budget_s
 
     # host cores actually usable: the affinity mask / cgroup quota, not the machine's core count
     # (256 intra-op threads on a 16-core share ran 20x slower than 16)
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            usable = max(1, min(usable, int(int(quota) / int(period))))
-    except Exception:
-        pass
+    usable = usable_host_cores()
     forward(0)                       # builds the sets this batch touches
     best = None
     for threads in sorted({min(usable, 8), min(usable, 16), min(usable, 32), usable}):
