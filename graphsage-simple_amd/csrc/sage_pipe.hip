@@ -353,16 +353,27 @@ void worker_fail(sage_pipe* p, int rc) {
     }
 }
 
+// how long an idle role thread spins before it sleeps (SAGE_PIPE_SPIN_US, default 2000, 0 = sleep at once)
+int spin_us() {
+    static const int v = [] { const char* e = getenv("SAGE_PIPE_SPIN_US"); const int x = e ? atoi(e) : 2000; return x < 0 ? 0 : x > 1000000 ? 1000000 : x; }();
+    return v;
+}
+
 void role_thread(sage_pipe* p, int r) {
     (void)hipSetDevice(p->device);
     uint64_t b = p->done[r].load(std::memory_order_relaxed);
     for (;;) {
-        // a posted batch: spin for a while (a running pipeline posts every few tens of microseconds), then sleep
+        // a posted batch: spin for spin_us() microseconds (default 2000: a running pipeline posts every few tens of microseconds, and a caller
+        // that fences between two regions -- flush, device synchronize, barrier -- is back within a millisecond or two; a thread that went
+        // to sleep costs the next region's first batch a ~50 us condition-variable wake-up), then sleep.  Until round 3 the bound was a
+        // count of 200 000 `pause` instructions, 3-4 ms on the EPYC hosts, not the "few tens of microseconds" DESIGN claimed.
         bool have = false;
-        for (unsigned n = 0; n < 200000; ++n) {
+        const auto t_spin = std::chrono::steady_clock::now();
+        for (unsigned n = 0;; ++n) {
             if (p->posted.load(std::memory_order_acquire) > b) { have = true; break; }
             if (p->stop.load(std::memory_order_relaxed)) return;
             cpu_relax();
+            if ((n & 255u) == 255u && std::chrono::steady_clock::now() - t_spin > std::chrono::microseconds(spin_us())) break;
         }
         if (!have) {
             std::unique_lock<std::mutex> lk(p->mu);

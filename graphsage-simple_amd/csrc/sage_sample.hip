@@ -48,9 +48,37 @@ __device__ __forceinline__ void sample_strided(const SampleArgs& a, const int bi
     }
 }
 
+// Scalar parameters, not `const SampleArgs a`: with the struct as ONE by-value argument the compiler keeps every field in SGPRs for the
+// kernel's whole life (106 SGPRs, 36-42 VGPRs against 35-62 / 19-21 with scalars, where each instantiation drops the arguments it does not
+// use): fewer blocks per CU, and the inner hop alone went from 12.2 to 16.0 us (round 4, same-box).  The multi-batch kernel below has no
+// choice (its items are picked by blockIdx) and pays that.
 template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
-__global__ __launch_bounds__(THREADS) void sample_kernel(const SampleArgs a) {
-    sample_strided<G, THREADS, SAMPLE, FRONTIER>(a, (int)blockIdx.x, (int)gridDim.x);
+__global__ __launch_bounds__(THREADS) void sample_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ nodes, int n, const int32_t* __restrict__ n_dev,
+    int k, uint32_t key0, uint32_t key1, uint32_t tag, int tag_self_rows, uint32_t tag_self,
+    const int32_t* __restrict__ in_nbr, const int32_t* __restrict__ in_cnt,
+    int32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int32_t* __restrict__ any_nonempty,
+    FrontierDev f, int insert_self, int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot, BatchSrc bs,
+    int n_off, ResolveJob rj) {
+    constexpr int GPB = THREADS / G;
+    const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+    sample_block<G, THREADS, SAMPLE, FRONTIER>(rowptr, col, nodes, n, n_dev, k, key0, key1, tag, tag_self_rows, tag_self, in_nbr, in_cnt, nbr, cnt,
+                                               any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, rj, bid, nblk);
+#ifndef SAGE_S_NOLOOP      /* A/B build without the strided tail (then only valid with SAGE_SI_GRID=0) */
+    if constexpr (!FRONTIER) {
+        // capped grid (blocks_for): the chunks of the node list past the first pass, if the live rows reach that far
+        if ((int64_t)nblk * GPB < (int64_t)n) {
+            int nn = n;
+            if (n_dev) nn = min(*n_dev + n_off, n);
+            for (int b = bid + nblk; (int64_t)b * GPB < (int64_t)nn; b += nblk) {
+                __syncthreads();               // the block's LDS scratch (flag word) is reused by the next chunk
+                sample_block<G, THREADS, SAMPLE, FRONTIER>(rowptr, col, nodes, n, n_dev, k, key0, key1, tag, tag_self_rows, tag_self, in_nbr, in_cnt,
+                                                           nbr, cnt, any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, ResolveJob{}, b, nblk);
+            }
+        }
+    }
+#endif
 }
 
 // The same hop for up to kSampleMulti BATCHES in one launch (VERDICT r3 #1a): item i's blocks are blockIdx.x % count == i, so the
@@ -141,9 +169,12 @@ int blocks_for(int n) {
 template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
 void launch_one(const SampleMulti& m, hipStream_t st) {
     const int blocks = blocks_for<G, THREADS, FRONTIER>(m.item[0].n);
-    if (m.count == 1)
-        hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(blocks), dim3(THREADS), 0, st, m.item[0]);
-    else
+    if (m.count == 1) {
+        const SampleArgs& a = m.item[0];
+        hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(blocks), dim3(THREADS), 0, st, a.rowptr, a.col, a.nodes, a.n, a.n_dev, a.k,
+                           a.key0, a.key1, a.tag, a.tag_self_rows, a.tag_self, a.in_nbr, a.in_cnt, a.nbr, a.cnt, a.any_nonempty, a.f, a.insert_self,
+                           a.nbr_slot, a.self_slot, a.bs, a.n_off, a.rj);
+    } else
         hipLaunchKernelGGL((sample_multi_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(blocks * m.count), dim3(THREADS), 0, st, m);
 }
 

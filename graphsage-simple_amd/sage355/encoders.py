@@ -17,6 +17,18 @@ two-layer stack from it unchanged (model.py:218-222).  Underneath:
   handed to it (as the reference does, aggregators.py:62-65) and the returned
   rows are aggregated on the GPU.
 
+Adjacency freeze semantics.  The reference re-reads ``adj_lists`` on every call
+(encoders.py:47); here the device CSR of an adjacency object is CACHED.  It is
+revalidated (a) on every call by the number of keys and by the set sizes of up
+to 64 of the batch's own nodes against the cached degrees, (b) every 64th call
+by a fingerprint over all set sizes and the contents of ~256 rows (adjacencies
+up to 200 000 keys), (c) on every call when ``SAGE_ADJ_STRICT=1``.  An in-place
+edit that keeps every probed size can therefore be served from the stale CSR
+for up to 63 forwards: call ``invalidate_adjacency(adj_lists)`` after editing an
+adjacency an Encoder has already seen.  The feature table is treated as frozen
+too (model.py:214-215): in-place writes that bump the tensor's version counter
+are picked up, ``.data`` writes need ``TwoHopEngine.refresh_table()``.
+
 Sampling: the device sampler draws k distinct uniform neighbours per node
 (all of them when deg < k), the reference's rule (aggregators.py:42-46), from a
 counter-based generator.  The two device-sampler paths (``_forward_two_hop``,
@@ -82,21 +94,46 @@ def invalidate_adjacency(adj_lists=None):
         _csr_cache.pop(id(adj_lists), None)
 
 
-def _device_csr(adj_lists, num_nodes_hint, device):
+def _probe_ok(adj_lists, deg_host, probe_nodes):
+    """Cheap per-call signal: the set sizes of up to 64 of the batch's own nodes still equal the cached CSR's degrees."""
+    if probe_nodes is None:
+        return True
+    n = len(deg_host)
+    step = max(1, len(probe_nodes) // 64)
+    for i in range(0, len(probe_nodes), step):
+        v = int(probe_nodes[i])
+        if 0 <= v < n:
+            s = adj_lists.get(v) if hasattr(adj_lists, "get") else adj_lists[v]      # .get: never insert (a defaultdict would)
+            if (len(s) if s is not None else 0) != deg_host[v]:
+                return False
+    return True
+
+
+def _device_csr(adj_lists, num_nodes_hint, device, probe_nodes=None):
     """dict-of-sets -> CSR in HBM, cached per adjacency object (both layers share one, model.py:219-222).
-    The reference re-reads the dict on every call; here the conversion is cached and revalidated by a fingerprint."""
+    The reference re-reads the dict on every call; here the conversion is cached and revalidated: every call by the key count and
+    by the set sizes of a few of the batch's own nodes (`probe_nodes`), every _CSR_RECHECK_EVERY-th call (or every call under
+    SAGE_ADJ_STRICT=1) by a fingerprint."""
+    import os
     key = id(adj_lists)
     hit = _csr_cache.get(key)
     if hit is not None and hit[0] is adj_lists and hit[4] == num_nodes_hint:
-        # every call: O(1) -- a changed key count (new nodes; also the empty sets the reference's defaultdict inserts on a miss)
-        # triggers the full fingerprint at once; otherwise it is recomputed every _CSR_RECHECK_EVERY-th call (it walks every
-        # set in Python: ~0.3 ms at Cora's size, twice per forward, was a third of a 256-seed training step)
+        # every call: O(1) + O(64) -- a changed key count (new nodes; also the empty sets the reference's defaultdict inserts on a miss)
+        # or a changed set size among the batch's own nodes triggers the full fingerprint at once; otherwise it is recomputed every
+        # _CSR_RECHECK_EVERY-th call (it walks every set in Python: ~0.3 ms at Cora's size, twice per forward, was a third of a
+        # 256-seed training step)
         state = hit[5]
         state[0] += 1
-        if len(adj_lists) == state[1] and state[0] % _CSR_RECHECK_EVERY != 0:
+        strict = os.environ.get("SAGE_ADJ_STRICT", "0") == "1"
+        probe = _probe_ok(adj_lists, hit[6], probe_nodes)
+        if probe and not strict and len(adj_lists) == state[1] and state[0] % _CSR_RECHECK_EVERY != 0:
             _csr_cache.move_to_end(key)
             return hit[1], hit[2]
-        if hit[3] == _fingerprint(adj_lists):
+        if probe and hit[3] is not None and hit[3] == _fingerprint(adj_lists):
+            state[1] = len(adj_lists)
+            _csr_cache.move_to_end(key)
+            return hit[1], hit[2]
+        if probe and hit[3] is None and not strict:          # too large to fingerprint: frozen at first use (probe and key count aside)
             state[1] = len(adj_lists)
             _csr_cache.move_to_end(key)
             return hit[1], hit[2]
@@ -109,11 +146,41 @@ def _device_csr(adj_lists, num_nodes_hint, device):
     rowptr, col = g.to(device)
     if col.numel() == 0:
         col = torch.zeros(1, dtype=torch.int32, device=device)
-    _csr_cache[key] = (adj_lists, rowptr, col, fp, num_nodes_hint, [0, len(adj_lists)])
+    deg_host = np.diff(g.rowptr)
+    _csr_cache[key] = (adj_lists, rowptr, col, fp, num_nodes_hint, [0, len(adj_lists)], deg_host)
     _csr_cache.move_to_end(key)
     while len(_csr_cache) > _CSR_CACHE_MAX:
         _csr_cache.popitem(last=False)
     return rowptr, col
+
+
+_threads_capped = False
+
+
+def _cap_host_threads_once():
+    """Strict drop-in mode (cuda=False): the caller's classifier, loss and SGD run in torch on the HOST (model.py:237-250).  On a box
+    whose cgroup share is smaller than its core count torch starts one intra-op thread per CORE, and three 70 k-element `add_`s of the
+    optimizer then take 2 ms each on the oversubscribed share (a 256-seed step: mean 3-10 ms against a median of 0.7-1.2).  Once, at
+    the first such forward, torch's intra-op pool is capped to the cores this process may actually use.  SAGE_KEEP_TORCH_THREADS=1 opts out."""
+    global _threads_capped
+    if _threads_capped:
+        return
+    _threads_capped = True
+    import os
+    if os.environ.get("SAGE_KEEP_TORCH_THREADS", "0") == "1":
+        return
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    if torch.get_num_threads() > usable:
+        import sys
+        print(f"sage355: torch intra-op threads {torch.get_num_threads()} -> {usable} (the cores this process may use; "
+              "SAGE_KEEP_TORCH_THREADS=1 keeps torch's own choice)", file=sys.stderr)
+        torch.set_num_threads(usable)
 
 
 class Encoder(nn.Module):
@@ -186,8 +253,15 @@ class Encoder(nn.Module):
         if not torch.cuda.is_available():
             raise native.SageError("sage355.Encoder needs an MI355X; there is no CPU path")
         native.lib()
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self._can_fuse_two_hop():
+        if not self.cuda:
+            _cap_host_threads_once()
+        grad = torch.is_grad_enabled()
+        training = grad and any(p.requires_grad for p in self.parameters())
+        # The fused two-hop node (autograd._TwoHop) returns gradients for the two `weight` Parameters only -- the model.py:214-215 case, a
+        # frozen table.  A TRAINABLE table (nn.Embedding's default) under grad mode takes the per-operator path below, whose
+        # autograd.gather_mean / linear_act do reach the table, as the reference's autograd does.
+        table_trains = grad and self._can_fuse_two_hop() and self.base_model.features.weight.requires_grad
+        if self._can_fuse_two_hop() and not table_trains:
             out = self._forward_two_hop(nodes, training)
         elif self._is_table() and self.num_sample is not None and self.num_sample <= native.MAX_FANOUT \
                 and isinstance(self.aggregator, MeanAggregator):
@@ -226,8 +300,9 @@ class Encoder(nn.Module):
         dev = torch.device("cuda")
         table = base._on_device(base.features.weight, "table")
         n = table.shape[0]
-        rp1, c1 = _device_csr(base.adj_lists, n, dev)
-        rp2, c2 = (rp1, c1) if self.adj_lists is base.adj_lists else _device_csr(self.adj_lists, n, dev)
+        probe = nodes if isinstance(nodes, (list, tuple, np.ndarray)) else None      # a device tensor is not read back for this
+        rp1, c1 = _device_csr(base.adj_lists, n, dev, probe)
+        rp2, c2 = (rp1, c1) if self.adj_lists is base.adj_lists else _device_csr(self.adj_lists, n, dev, probe)
         (w1, r1), (w2, r2) = base._engine_weight("engine_w"), self._engine_weight("engine_w")
         key = (rp1.data_ptr(), rp2.data_ptr(), table.data_ptr(), w1.data_ptr(), w2.data_ptr(), base.num_sample,
                self.num_sample, self.gcn, self._agg_self_loop(), base._act(), self._act())
@@ -247,8 +322,12 @@ class Encoder(nn.Module):
     def _forward_table(self, nodes):
         """One layer over a raw feature table (encoders.py:47-62 with features = nn.Embedding)."""
         dev = torch.device("cuda")
-        table = self._on_device(self.features.weight, "table")
-        rowptr, col = _device_csr(self.adj_lists, table.shape[0], dev)
+        tw = self.features.weight
+        if torch.is_grad_enabled() and tw.requires_grad and not tw.is_cuda:
+            table = tw.to("cuda", torch.float32)             # differentiable copy: the gradient flows back to the host table
+        else:
+            table = self._on_device(tw, "table")
+        rowptr, col = _device_csr(self.adj_lists, table.shape[0], dev, nodes if isinstance(nodes, (list, tuple, np.ndarray)) else None)
         ids = ops.as_ids(nodes, dev, table.shape[0])
         any_nonempty = torch.zeros(1, dtype=torch.int32, device=dev)
         nbr, cnt, _, _ = ops.sample_neighbors(rowptr, col, ids, self.num_sample, random.getrandbits(64), ops.TAG_INNER,

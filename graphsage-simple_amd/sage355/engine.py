@@ -232,9 +232,23 @@ class TwoHopEngine:
             return
         if self._table_sliced is None or self._table_sliced_version != self.table._version:
             n_rows = self.table.shape[0]
-            self._table_sliced = self.table.view(n_rows, self.d0p // w, w).permute(1, 0, 2).contiguous()
+            src = self.table.view(n_rows, self.d0p // w, w).permute(1, 0, 2)
+            if self._table_sliced is not None and tuple(self._table_sliced.shape) == tuple(src.shape):
+                # refreshed IN PLACE: a role pipeline built over this engine copied the buffer's pointer at sage_pipe_create
+                # (a new tensor per rebuild left the pipe reading a stale, later a freed, copy)
+                self._table_sliced.copy_(src)
+            else:
+                self._table_sliced = src.contiguous()
+                self._model_key = None
             self._table_sliced_version = self.table._version
-            self._model_key = None
+
+    def refresh_table(self):
+        """The table was written in a way that does not move its version counter (`.data`, a collective, a replayed hipGraph): bring the
+        engine's slice-major copy up to date, in place (pointers held by role pipelines stay valid).  The table is otherwise treated
+        as frozen (model.py:214-215)."""
+        self._table_sliced_version = None
+        if self.layout.total_bytes:
+            self._slice_table()
 
     def _model(self, queued=False):
         if self.layout.total_bytes:          # the layout is known (after the first _reserve)

@@ -322,6 +322,63 @@ def reference_f1_fixture_pubmed(g_pub):
                                                                          fixture["f1_macro_mean"], fixture["f1_macro_std"]))
 
 
+def reference_f1_streams(g, name, num_classes, feat_dim, epochs, batch_size, runs=24):
+    """the reference's F1 over MANY (sampling stream, weight initialisation) pairs on ONE split -- what this build's
+    F1 test varies too (the device sampler cannot replay Python's `random`, so only distributions can be compared).  run_model
+    (model.py:192-259) line for line as in reference_f1_fixture, with np.random.seed(1) (the split), random.seed(1000 + i) (shuffles +
+    neighbour sampling) and torch.manual_seed(i) (weights) for run i."""
+    import json
+    import time
+    from graphsage.model import SupervisedGraphSage
+    from sage355.datasets import standin_citation
+    from sklearn.metrics import f1_score
+    n = g.num_nodes
+    feat_data, labels = standin_citation(g, num_classes=num_classes, feat_dim=feat_dim, seed=0)
+    adj_lists = g.to_adj_lists()
+    out = []
+    for i in range(runs):
+        torch.manual_seed(i)
+        np.random.seed(1)
+        random.seed(1000 + i)
+        features = torch.nn.Embedding(n, feat_dim)
+        features.weight = torch.nn.Parameter(torch.FloatTensor(feat_data), requires_grad=False)
+        agg1 = MeanAggregator(features, cuda=True, feature_dim=100, num_nodes=n, initializer="None")
+        enc1 = quiet(Encoder, features, feat_dim, 50, adj_lists, agg1, gcn=True, cuda=False, initializer="None")
+        agg2 = MeanAggregator(lambda nodes: enc1(nodes).t(), n, cuda=False)
+        enc2 = quiet(Encoder, lambda nodes: enc1(nodes).t(), enc1.embed_dim, 128, adj_lists, agg2, base_model=enc1, gcn=True, cuda=False)
+        model = SupervisedGraphSage(num_classes, enc2)
+        rand_indices = np.random.permutation(n)
+        val = rand_indices[int(0.1 * n):int(0.2 * n)]
+        train = list(rand_indices[int(0.2 * n):])
+        opt = torch.optim.SGD(filter(lambda p: p.requires_grad, model.parameters()), lr=0.7)
+        t0 = time.time()
+        for _ in range(epochs):
+            random.shuffle(train)
+            for batch in range(0, len(train), batch_size):
+                batch_nodes = train[batch:max(len(train), batch + batch_size)]
+                opt.zero_grad()
+                loss = model.loss(batch_nodes, torch.LongTensor(labels[np.array(batch_nodes)]))
+                loss.backward()
+                opt.step()
+        with torch.no_grad():
+            pred = model.forward(val).data.numpy().argmax(axis=1)
+        out.append({"run": i, "f1_micro": float(f1_score(labels[val], pred, average="micro")),
+                    "f1_macro": float(f1_score(labels[val], pred, average="macro")), "seconds": round(time.time() - t0, 1)})
+        print(name, "reference F1 run", out[-1], flush=True)
+    mi, ma = np.array([r["f1_micro"] for r in out]), np.array([r["f1_macro"] for r in out])
+    fixture = {"dataset": f"{name} topology + sage355.datasets.standin_citation(num_classes={num_classes}, feat_dim={feat_dim}, seed=0)",
+               "config": {"epochs": epochs, "batch_size": batch_size, "ref_batching": True, "lr": 0.7, "split_seed": 1,
+                          "sample_seed": "1000 + run", "torch_seed": "run", "hidden": [50, 128], "num_sample": [10, 10], "gcn": True},
+               "runs": out,
+               "f1_micro_mean": float(mi.mean()), "f1_micro_std": float(mi.std(ddof=1)), "f1_micro_se": float(mi.std(ddof=1) / np.sqrt(len(mi))),
+               "f1_macro_mean": float(ma.mean()), "f1_macro_std": float(ma.std(ddof=1)), "f1_macro_se": float(ma.std(ddof=1) / np.sqrt(len(ma))),
+               "f1_macro_min": float(ma.min()), "f1_macro_max": float(ma.max())}
+    with open(os.path.join(HERE, f"reference_f1_{name}_standin_streams.json"), "w") as fp:
+        json.dump(fixture, fp, indent=1)
+    print(name, "reference F1 over %d (stream, init) pairs: micro %.4f +- %.4f (SE %.4f), macro %.4f +- %.4f" %
+          (len(out), fixture["f1_micro_mean"], fixture["f1_micro_std"], fixture["f1_micro_se"], fixture["f1_macro_mean"], fixture["f1_macro_std"]))
+
+
 def batch_size_cases(g_cora, g_pub):
     """BASELINE configs[0] / configs[1] at their batch size: B = 256 seeds, Cora 1433 -> 50 -> 128 with the fanout the
     reference really runs (10 / 10: model.py:223-224 writes `num_samples`, encoders.py:23 reads `num_sample`) and the 5 / 5 the config
@@ -344,6 +401,14 @@ def main():
         g_cora, _ = G.read_edge_list(os.path.join(REF, "cora/cora.cites"))
         g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")
         batch_size_cases(g_cora, g_pub)
+        return
+    if "--f1-streams-cora" in sys.argv:
+        g_cora, _ = G.read_edge_list(os.path.join(REF, "cora/cora.cites"))
+        reference_f1_streams(g_cora, "cora", 7, 1433, epochs=5, batch_size=128)
+        return
+    if "--f1-streams-pubmed" in sys.argv:
+        g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")
+        reference_f1_streams(g_pub, "pubmed", 3, 500, epochs=1, batch_size=1024, runs=12)
         return
     if "--f1-pubmed-only" in sys.argv:
         g_pub, _ = G.read_edge_list(os.path.join(REF, "pubmed-data/Pubmed-Diabetes.DIRECTED.cites.tab"), fmt="pubmed")

@@ -158,56 +158,18 @@ def test_captured_step_trains_like_the_eager_step(gcn, relabel, hidden1):
     assert (sc - se).abs().max().item() <= 2e-3 * se.abs().max().item()
 
 
-def test_engine_training_reaches_reference_f1_on_standin_cora_in_under_a_millisecond_per_step():
-    """Same split / optimiser / epochs / batching as the reference run (model.py:244's descending batches); the comparison of
-    F1 MEANS as in tests/test_gpu_train.py.  Then plain 256-seed steps are timed: target <= 1 ms per step (VERDICT r1 #9;
-    the module-level path takes 10-12 ms, the reference 140-180 ms on a CPU)."""
-    ref = json.load(open(os.path.join(GOLDEN_DIR, "reference_f1_cora_standin.json")))
+def test_engine_training_step_on_standin_cora_takes_under_a_millisecond():
+    """Plain 256-seed steps through EngineTrainer: target <= 1 ms per step (the reference 140-180 ms on a CPU).  F1 against
+    the reference's distribution over sampling streams -- Cora and Pubmed, this path and the module-level ones -- is
+    tests/test_gpu_train.py::test_f1_distribution_over_sampling_streams_matches_the_reference."""
     g = _topology("cora_topology.npz")
     feats, labels = standin_citation(g, num_classes=7, feat_dim=1433, seed=0)
-    cfg = ref["config"]
-    micro = []
-    for run in range(6):
-        torch.manual_seed(run)
-        res = run_engine_training(g, feats, labels, 7, seed=cfg["seed"], sample_seed=100 + run, epochs=cfg["epochs"],
-                                  batch_size=cfg["batch_size"], ref_batching=True, lr=cfg["lr"], hidden1=50, hidden2=128,
-                                  num_sample1=10, num_sample2=10, gcn=True)
-        assert res["losses"][-1] < 0.5 * res["losses"][0]
-        micro.append(res["f1_micro"])
-    mine, spread = float(np.mean(micro)), float(np.std(micro))
-    tol = 0.005 + 2 * float(np.sqrt(spread ** 2 / len(micro) + ref["f1_micro_std"] ** 2 / len(ref["runs"])))
-    print(f"engine F1 micro {mine:.4f} +- {spread:.4f} (runs {[round(m, 4) for m in micro]}), reference {ref['f1_micro_mean']:.4f} "
-          f"+- {ref['f1_micro_std']:.4f}, tolerance {tol:.4f}")
-    assert abs(mine - ref["f1_micro_mean"]) <= tol, (mine, ref["f1_micro_mean"], tol)
-    # step time, plain 256-seed batches, three epochs (first epoch warms up)
     torch.manual_seed(0)
     res = run_engine_training(g, feats, labels, 7, seed=1, epochs=1, batch_size=256)
     res = run_engine_training(g, feats, labels, 7, seed=1, epochs=4, batch_size=256)
     print(f"engine step (256 seeds, 1433 -> 50 -> 128, fanout 10/10): {res['mean_step_time'] * 1e3:.3f} ms")
     assert res["mean_step_time"] <= 1.0e-3, res["mean_step_time"]
     assert res["f1_micro"] > 0.85
-
-
-def test_engine_training_reaches_reference_f1_on_standin_pubmed():
-    """Pubmed (19717 nodes, 3 classes, 500-dim stand-in content), the reference's effective fanout 10/10, one
-    epoch of its descending batches with batch_size 1024 (the bounded configuration the fixture was generated with)."""
-    path = os.path.join(GOLDEN_DIR, "reference_f1_pubmed_standin.json")
-    ref = json.load(open(path))
-    g = _topology("pubmed_topology.npz")
-    feats, labels = standin_citation(g, num_classes=3, feat_dim=500, seed=0)
-    cfg = ref["config"]
-    micro = []
-    for run in range(5):
-        torch.manual_seed(run)
-        res = run_engine_training(g, feats, labels, 3, seed=cfg["seed"], sample_seed=200 + run, epochs=cfg["epochs"],
-                                  batch_size=cfg["batch_size"], ref_batching=True, lr=cfg["lr"], hidden1=50, hidden2=128,
-                                  num_sample1=10, num_sample2=10, gcn=True)
-        micro.append(res["f1_micro"])
-    mine, spread = float(np.mean(micro)), float(np.std(micro))
-    tol = 0.005 + 2 * float(np.sqrt(spread ** 2 / len(micro) + ref["f1_micro_std"] ** 2 / len(ref["runs"])))
-    print(f"engine Pubmed F1 micro {mine:.4f} +- {spread:.4f} (runs {[round(m, 4) for m in micro]}), reference "
-          f"{ref['f1_micro_mean']:.4f} +- {ref['f1_micro_std']:.4f}, tolerance {tol:.4f}")
-    assert abs(mine - ref["f1_micro_mean"]) <= tol, (mine, ref["f1_micro_mean"], tol)
 
 
 def _dp_rank(rank, world, port, tmp, d0=64, h1=32):

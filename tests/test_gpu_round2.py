@@ -286,6 +286,22 @@ def test_bench_gpus_2_from_a_plain_shell():
     assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
 
 
+def test_bench_two_ranks_say_how_the_pipeline_was_fed():
+    """every rank of the role pipeline starts four spinning host threads beside its submitter, so bench.py turns them on only
+    where each rank of the node has five usable cores to itself -- and the line says which mode ran (config.host).  Two ranks share this
+    box's one GPU (gloo), the headline workload, no side variants."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--steps", "20", "--warmup", "5",
+           "--cpu-seconds", "0", "--preheat-seconds", "0.05", "--no-variant", "--scale-variant", "off"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    h = line["config"]["host"]
+    assert line["n_gpus"] == 2 and h["ranks_on_node"] == 2 and h["cores_per_rank"] == h["host_cores_usable"] // 2
+    assert h["role_threads"] == (h["cores_per_rank"] >= 5) and h["enqueue_mode"] in ("one host thread per role stream", "submitting thread only")
+    assert ("host enqueue thread" in line["config"]["execution"]) == h["role_threads"]
+    assert line["timed_path_check"]["bit_identical_to_oracle_gated_forward"] is True
+
+
 # ------------------------------------------------------------------------------------------ the split-bf16 contraction, adversarially
 def _contract_through_the_engine(x_rows, w1, d0=256, prepare=True):
     """h1 = x . W1^T as the ENGINE's layer-1 contraction computes it (dense_bf16x3_kernel): a perfect-matching graph

@@ -119,7 +119,7 @@ def test_module_training_path_through_the_engine_matches_reference_gradients(nam
 
 
 def _reference_loop(feat_data, labels, adj_lists, num_classes, seed, sample_seed, epochs, batch_size, ref_batching, lr=0.7,
-                    hidden1=50, num_sample=10):
+                    hidden1=50, num_sample=10, with_macro=False):
     """graphsage/model.py:192-259 restated with the DROP-IN classes (`from graphsage.encoders import Encoder`, the shim package of
     INTEGRATION.md A) and cuda=False everywhere, as model.py:218-222 effectively runs: seeds, split, SGD lr 0.7, the per-step
     wall clock around loss / backward / step, F1 on the validation split."""
@@ -158,52 +158,44 @@ def _reference_loop(feat_data, labels, adj_lists, num_classes, seed, sample_seed
             times.append(time.time() - start_time)
             losses.append(loss.item())
     val_output = graphsage.forward(val)
-    f1 = f1_score(np.asarray(labels)[val].reshape(-1), val_output.data.numpy().argmax(axis=1), average="micro")
+    pred = val_output.data.numpy().argmax(axis=1)
+    f1 = f1_score(np.asarray(labels)[val].reshape(-1), pred, average="micro")
+    if with_macro:                                  # model.py:258 prints it too
+        return f1, times, losses, enc2, f1_score(np.asarray(labels)[val].reshape(-1), pred, average="macro")
     return f1, times, losses, enc2
 
 
 def test_reference_loop_shape_with_the_drop_in_classes_trains_at_engine_speed():
     """The reference's training loop (model.py:240-252), its classes swapped for the drop-in ones by the import line alone,
-    cuda=False: (a) F1 on stand-in Cora by the rule of tests/test_gpu_train.py (means over six sampling streams against the
-    REFERENCE's five runs); (b) <= 1.5 ms per 256-seed step (the reference: 140-180 ms per step on a CPU; this
-    path before round 3: 10-12 ms, layer 2 sampled by Python sets)."""
-    import json
+    cuda=False: <= 1.5 ms per 256-seed step in the median AND <= 2.5 ms in the mean (the reference: 140-180 ms per step on a CPU,
+    SURVEY 8c; this path before round 3: 10-12 ms, layer 2 sampled by Python sets).  The F1 of this very loop against the reference's
+    distribution over sampling streams is tests/test_gpu_train.py::test_f1_distribution_over_sampling_streams_matches_the_reference
+    (path "dropin").
+    The mean: the classifier, the loss and SGD of this loop are stock torch ops on the HOST (cuda=False, as model.py
+    runs).  On a GPU box torch sees 256 cores behind a 16-core share, and three 70 k-element `add_`s on 256 oversubscribed threads
+    took 2 ms each (mean 3-10 ms at a median of 0.7-1.2).  Since round 4 the PRODUCT caps torch's intra-op pool to the usable cores at
+    the first cuda=False forward (encoders._cap_host_threads_once), so the test no longer sets the thread count itself."""
+    from sage355 import encoders
     from sage355.datasets import standin_citation
     from sage355.graph import CSRGraph
+    from util import usable_cores
     z = np.load(os.path.join(GOLDEN_DIR, "cora_topology.npz"))
     g = CSRGraph(z["rowptr"], z["col"], len(z["rowptr"]) - 1)
     feats, labels = standin_citation(g, num_classes=7, feat_dim=1433, seed=0)
     adj = g.to_adj_lists()
-    ref = json.load(open(os.path.join(GOLDEN_DIR, "reference_f1_cora_standin.json")))
-    cfg = ref["config"]
-    micro = []
-    for run in range(6):
-        torch.manual_seed(run)
-        f1, _, losses, enc2 = _reference_loop(feats, labels, adj, 7, cfg["seed"], 1000 + run, cfg["epochs"], cfg["batch_size"], True, lr=cfg["lr"])
-        assert enc2._engine is not None and enc2._engine.generation > 0 and losses[-1] < 0.5 * losses[0]
-        micro.append(f1)
-    mine, spread = float(np.mean(micro)), float(np.std(micro))
-    tol = 0.005 + 2 * float(np.sqrt(spread ** 2 / len(micro) + ref["f1_micro_std"] ** 2 / len(ref["runs"])))
-    print(f"drop-in loop F1 micro {mine:.4f} +- {spread:.4f} (runs {[round(m, 4) for m in micro]}), reference {ref['f1_micro_mean']:.4f} "
-          f"+- {ref['f1_micro_std']:.4f}, tolerance {tol:.4f}")
-    assert abs(mine - ref["f1_micro_mean"]) <= tol, (mine, ref["f1_micro_mean"], tol)
-    # The classifier, the loss and SGD of this loop are stock torch ops on the HOST (cuda=False, as model.py runs): give them the
-    # cores this process really has -- on a GPU box torch sees 256 cores behind a 16-core share, and three 70 k-element `add_`s on
-    # 256 oversubscribed threads took 2 ms each (cProfile, experiments/r03/prof_dropin.py: median step 1.15 ms, mean 10.7 ms)
-    from util import usable_cores
     threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(8, usable_cores())))
+    encoders._threads_capped = False               # as in a fresh process: the first cuda=False forward caps the pool
     try:
         torch.manual_seed(0)
-        f1, times, losses, _ = _reference_loop(feats, labels, adj, 7, 1, 1, 4, 256, False)
+        f1, times, losses, enc2 = _reference_loop(feats, labels, adj, 7, 1, 1, 4, 256, False)
+        assert torch.get_num_threads() <= usable_cores()
     finally:
         torch.set_num_threads(threads)
+    assert enc2._engine is not None and enc2._engine.generation > 0
     steady = times[len(times) // 4:]               # the first epoch warms up (engine construction, CSR conversion, allocator)
-    # Judged on the median and the 80th percentile: the loop's host side shares its cores with whatever else runs on the box, and a
-    # few steps of tens of milliseconds (seen: mean 3.15 ms at a median of 0.69 ms) say nothing about this path
-    per_step, p80 = float(np.median(steady)), float(np.percentile(steady, 80))
-    print(f"drop-in loop: median {per_step * 1e3:.3f} ms per 256-seed step (80th percentile {p80 * 1e3:.3f}, mean {np.mean(steady) * 1e3:.3f}), F1 {f1:.3f}")
-    assert per_step <= 1.5e-3 and p80 <= 3e-3, (per_step, p80)
+    per_step, p80, mean = float(np.median(steady)), float(np.percentile(steady, 80)), float(np.mean(steady))
+    print(f"drop-in loop: median {per_step * 1e3:.3f} ms per 256-seed step (80th percentile {p80 * 1e3:.3f}, mean {mean * 1e3:.3f}), F1 {f1:.3f}")
+    assert per_step <= 1.5e-3 and p80 <= 3e-3 and mean <= 2.5e-3, (per_step, p80, mean)
     assert f1 > 0.85 and np.mean(losses[-5:]) < 0.6 * np.mean(losses[:5])
 
 
@@ -584,7 +576,7 @@ def test_bench_line_as_the_driver_runs_it_keeps_the_contract():
     line on stdout with the contract's keys, BASELINE's metric on configs[2], `roofline` and `cpu_baseline` objects whose figures are
     consistent with each other, the timed path's output checked bit for bit, and the 1e-5 parity gate passed."""
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--gpus", "1",
-                        "--steps", "20", "--warmup", "5", "--cpu-seconds", "3"], capture_output=True, text=True, timeout=600)
+                        "--steps", "20", "--warmup", "5", "--cpu-seconds", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -596,7 +588,6 @@ def test_bench_line_as_the_driver_runs_it_keeps_the_contract():
     assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["dtype"], d["data"], d["vs_baseline"]) == (1, 20, 5, "weak", "f32", "synthetic", None)
     cfg = d["config"]
     assert "BASELINE configs[2]" in cfg["workload"] and "model" not in cfg and cfg["batch_per_gpu"] == 4096 and cfg["fanout"] == [15, 25]
-    assert "host enqueue thread" in cfg["execution"]                       # the path the round-3 tests above check against the oracle
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     assert d["parity_max_err_vs_fp64_oracle"] <= 1e-5 and d["timed_path_check"]["bit_identical_to_oracle_gated_forward"] is True
     ro = d["roofline"]
@@ -608,6 +599,19 @@ def test_bench_line_as_the_driver_runs_it_keeps_the_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "embeddings/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 1000 * cb["value"]                                 # (a sanity bound, not a target)
+    # round 4: BASELINE configs[3] -- the scaling curve's workload -- rides in the N = 1 line, measured by the same code
+    v = cfg["variants"]["configs3_rmat23"]
+    assert "BASELINE configs[3]" in v["workload"] and "2^23" in v["workload"] and v["n_gpus"] == 1
+    assert abs(v["value"] - 4096 / (v["ms_per_step"] * 1e-3)) <= 1e-3 * v["value"]
+    assert v["parity_max_err_vs_fp64_oracle"] <= 1e-5 and v["timed_path_check"]["bit_identical_to_oracle_gated_forward"] is True
+    assert abs(v["forward_frac"] - v["forward_bytes"] / (v["ms_per_step"] * 1e-3) / 8e12) < 1e-3 and 0.05 < v["forward_frac"] < 1.0
+    vr = v["roofline"]
+    assert vr["bound"] == "hbm" and abs(vr["achieved"] - vr["bytes_per_launch"] / (vr["kernel_ms"] * 1e-3) / 1e9) <= 1e-2 * vr["achieved"]
+    assert v["forward_bytes"] > d["roofline"]["forward_bytes"]           # an 8 x larger graph: fewer duplicates per batch, more unique rows
+    # ... and the line says how the pipeline was fed
+    h = cfg["host"]
+    assert h["ranks_on_node"] == 1 and h["cores_per_rank"] == h["host_cores_usable"] and h["role_threads"] == (h["cores_per_rank"] >= 5)
+    assert ("host enqueue thread" in cfg["execution"]) == h["role_threads"]
 
 
 # ------------------------------------------------------------------------------------------ inference on a pre-transformed table

@@ -1,9 +1,8 @@
-"""Training harness on the MI355X vs the reference's F1 on the same stand-in dataset
-(tests/golden/reference_f1_cora_standin.json: the REFERENCE trained here on cora.cites topology +
-synthesised content, five torch seeds).  BASELINE.json: "Cora F1 within +-0.5 of the CPU reference"
--- the real content files are not available offline, so this is the
-closest pinned statement; the tolerance below is 0.5 points plus twice the reference's own
-seed-to-seed spread."""
+"""Training harness on the MI355X vs the reference's F1 on the same stand-in datasets
+(tests/golden/reference_f1_<dataset>_standin_streams.json: the REFERENCE trained here on the real cora.cites / Pubmed
+topology + synthesised content over 24 / 12 (sampling stream, weight initialisation) pairs).  BASELINE.json: "Cora/Pubmed
+F1 within +-0.5 of the CPU reference" -- the real content files are not available offline, so
+this is the closest pinned statement."""
 import json
 import os
 import random
@@ -27,28 +26,64 @@ def cora():
     return g, feats, labels
 
 
-def test_training_reaches_reference_f1_on_standin_cora():
-    """Same split, optimiser, epochs and batching as the reference run; six different sampling streams /
-    weight initialisations.  The device sampler cannot replay Python's `random`, so the comparison is
-    between MEANS: |mean F1 - reference mean| <= 0.5 points + 2 standard errors (measured spread over
-    sampling streams is ~0.9 points, the reference's five runs share ONE stream and spread 0.3)."""
-    ref = json.load(open(os.path.join(GOLDEN_DIR, "reference_f1_cora_standin.json")))
-    g, feats, labels = cora()
-    adj = g.to_adj_lists()
-    cfg = ref["config"]
-    micro = []
-    for run in range(6):
-        torch.manual_seed(run)
-        res = run_training(feats, labels, adj, 7, seed=cfg["seed"], sample_seed=1000 + run, epochs=cfg["epochs"],
-                           batch_size=cfg["batch_size"], ref_batching=True, lr=cfg["lr"], verbose=False, hidden1=50,
-                           hidden2=128, num_sample1=10, num_sample2=10, gcn=True)
-        assert res["losses"][-1] < 0.5 * res["losses"][0]
+def _f1_runs(path, graph, feats, labels, num_classes, runs, epochs, batch_size):
+    """path "engine": EngineTrainer (everything on the device); "modules": the reference's class surface on the device (run_training:
+    Encoder / MeanAggregator / SupervisedGraphSage, the two-hop forward and backward as one autograd node over the same engine);
+    "dropin": the reference's loop over the shim classes with cuda=False (host classifier / loss / SGD, as model.py runs)."""
+    from sage355.train import run_engine_training
+    micro, macro = [], []
+    adj = graph.to_adj_lists() if path != "engine" else None
+    for i in range(runs):
+        torch.manual_seed(i)                          # weight initialisation, as the fixture's run i
+        if path == "engine":
+            res = run_engine_training(graph, feats, labels, num_classes, seed=1, epochs=epochs, batch_size=batch_size, ref_batching=True,
+                                      sample_seed=1000 + i, hidden1=50, hidden2=128, num_sample1=10, num_sample2=10, gcn=True)
+        elif path == "dropin":
+            from test_gpu_round3 import _reference_loop       # model.py:192-259 restated over the shim classes, cuda=False
+            f1, _, losses, _, f1_macro = _reference_loop(feats, labels, adj, num_classes, 1, 1000 + i, epochs, batch_size, True, lr=0.7, with_macro=True)
+            res = {"f1_micro": f1, "f1_macro": f1_macro, "losses": losses}
+        else:
+            res = run_training(feats, labels, adj, num_classes, seed=1, sample_seed=1000 + i, epochs=epochs, batch_size=batch_size,
+                               ref_batching=True, lr=0.7, verbose=False, hidden1=50, hidden2=128, num_sample1=10, num_sample2=10, gcn=True)
+        assert res["losses"][-1] < 0.6 * res["losses"][0]
         micro.append(res["f1_micro"])
-    mine, spread = float(np.mean(micro)), float(np.std(micro))
-    tol = 0.005 + 2 * float(np.sqrt(spread ** 2 / len(micro) + ref["f1_micro_std"] ** 2 / len(ref["runs"])))
-    print(f"F1 micro: this build {mine:.4f} +- {spread:.4f} (runs {[round(m, 4) for m in micro]}), "
-          f"reference {ref['f1_micro_mean']:.4f} +- {ref['f1_micro_std']:.4f}, tolerance {tol:.4f}")
-    assert abs(mine - ref["f1_micro_mean"]) <= tol, (mine, ref["f1_micro_mean"], tol)
+        macro.append(res["f1_macro"])
+    return np.array(micro), np.array(macro)
+
+
+@pytest.mark.parametrize("dataset,path", [("cora", "engine"), ("cora", "modules"), ("cora", "dropin"), ("pubmed", "engine")])
+def test_f1_distribution_over_sampling_streams_matches_the_reference(dataset, path):
+    """"F1 within +-0.5 of the CPU reference", settled over MANY sampling streams on both sides.  The device sampler
+    cannot replay Python's `random`, so what can be compared is the F1 DISTRIBUTION over (sampling stream, weight initialisation)
+    pairs on one split: the reference's own (tests/golden/reference_f1_<dataset>_standin_streams.json: run_model line for line,
+    np.random.seed(1), random.seed(1000 + i), torch.manual_seed(i); 24 runs on Cora, 12 on Pubmed) against EngineTrainer with the same
+    split, epochs, descending batches (model.py:244), lr, fanout 10 / 10 and as many streams.
+    Bars: |mean micro F1 - reference mean| <= 0.5 points + 2 standard errors of the difference's SMALLER side; mean macro F1 (model.py:258
+    prints it too) within one standard deviation of the reference's single runs; spreads of the same order.
+    (Round 3 compared six streams with a fixture of five runs that shared ONE stream, random.seed(1): 0.9373 +- 0.0033.  Over 24 streams
+    the reference itself reads 0.9311 +- 0.0069 on stand-in Cora: that fixture sat on a lucky stream, there was no offset to explain.)"""
+    ref = json.load(open(os.path.join(GOLDEN_DIR, f"reference_f1_{dataset}_standin_streams.json")))
+    if dataset == "cora":
+        g, feats, labels = cora()
+        classes = 7
+    else:
+        z = np.load(os.path.join(GOLDEN_DIR, "pubmed_topology.npz"))
+        g = CSRGraph(z["rowptr"], z["col"], len(z["rowptr"]) - 1)
+        feats, labels = standin_citation(g, num_classes=3, feat_dim=500, seed=0)
+        classes = 3
+    cfg = ref["config"]
+    runs = len(ref["runs"])
+    micro, macro = _f1_runs(path, g, feats, labels, classes, runs, cfg["epochs"], cfg["batch_size"])
+    se_mine = float(micro.std(ddof=1) / np.sqrt(runs))
+    tol = 0.005 + 2 * min(se_mine, ref["f1_micro_se"])
+    d_micro = float(micro.mean()) - ref["f1_micro_mean"]
+    d_macro = float(macro.mean()) - ref["f1_macro_mean"]
+    print(f"{dataset} ({path}): F1 micro {micro.mean():.4f} +- {micro.std(ddof=1):.4f} (SE {se_mine:.4f}) vs reference {ref['f1_micro_mean']:.4f} +- "
+          f"{ref['f1_micro_std']:.4f} (SE {ref['f1_micro_se']:.4f}): delta {d_micro:+.4f}, bar {tol:.4f}; macro {macro.mean():.4f} +- {macro.std(ddof=1):.4f} vs "
+          f"{ref['f1_macro_mean']:.4f} +- {ref['f1_macro_std']:.4f}: delta {d_macro:+.4f}, {runs} streams each")
+    assert abs(d_micro) <= tol, (d_micro, tol)
+    assert abs(d_macro) <= ref["f1_macro_std"], (d_macro, ref["f1_macro_std"])
+    assert micro.std(ddof=1) <= 2.0 * ref["f1_micro_std"] + 0.002
 
 
 def test_plain_batching_and_eval_fast_path():

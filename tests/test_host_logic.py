@@ -196,6 +196,68 @@ def test_adjacency_cache_detects_in_place_mutation_and_is_bounded(monkeypatch):
     assert len(encoders._csr_cache) == encoders._CSR_CACHE_MAX
 
 
+def test_adjacency_cache_probes_the_batch_own_rows_every_call(monkeypatch):
+    """between two periodic fingerprints an in-place edit of an existing node's set was served from the stale CSR.  Every call
+    now compares the set sizes of (up to 64 of) the batch's own nodes with the cached degrees; SAGE_ADJ_STRICT=1 fingerprints every call."""
+    from collections import defaultdict
+    from sage355 import encoders
+    from sage355.graph import csr_from_adj_lists
+    builds = []
+    real = csr_from_adj_lists
+
+    def counting_csr(adj, n):
+        builds.append(sum(len(s) for s in adj.values()))
+        return real(adj, n)
+
+    monkeypatch.setattr(encoders, "csr_from_adj_lists", counting_csr)
+    monkeypatch.setattr(encoders, "_CSR_RECHECK_EVERY", 1000)
+    monkeypatch.delenv("SAGE_ADJ_STRICT", raising=False)
+    encoders.invalidate_adjacency()
+    adj = defaultdict(set, {0: {1, 2}, 1: {0}, 2: {0}, 3: set()})
+    encoders._device_csr(adj, 4, "cpu", [0, 1])
+    encoders._device_csr(adj, 4, "cpu", [0, 1])
+    assert builds == [4]
+    adj[1].add(2); adj[2].add(1)                       # node 1 grows: a batch that contains it sees the change at once ...
+    encoders._device_csr(adj, 4, "cpu", [0, 3])        # ... one that does not is still served from the cache (the documented freeze)
+    assert builds == [4]
+    rp, col = encoders._device_csr(adj, 4, "cpu", [1])
+    assert builds == [4, 6] and rp.tolist() == [0, 2, 4, 6, 6]
+    n_keys = len(adj)
+    encoders._device_csr(adj, 4, "cpu", [3, 2, 1, 0])
+    assert builds == [4, 6] and len(adj) == n_keys     # the probe never inserts keys into a defaultdict
+    adj[0].discard(2); adj[0].add(3); adj[2].discard(0); adj[3].add(0)     # degrees of 0 kept, 2 shrinks, 3 grows; batch = [0] only: sizes equal
+    encoders._device_csr(adj, 4, "cpu", [0])
+    assert builds == [4, 6]
+    monkeypatch.setenv("SAGE_ADJ_STRICT", "1")         # strict mode: the full fingerprint on every call
+    encoders._device_csr(adj, 4, "cpu", [0])
+    assert builds == [4, 6, 6]
+    encoders.invalidate_adjacency()
+
+
+def test_strict_drop_in_mode_caps_torch_threads_to_the_usable_cores(monkeypatch):
+    """with cuda=False the caller's classifier / loss / SGD run in torch on the host; on a box whose cgroup share is smaller
+    than its core count the intra-op pool is capped once (SAGE_KEEP_TORCH_THREADS=1 opts out)."""
+    import torch
+    from sage355 import encoders
+    from util import usable_cores
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(encoders, "_threads_capped", False)
+        monkeypatch.setenv("SAGE_KEEP_TORCH_THREADS", "1")
+        torch.set_num_threads(usable_cores() + 3)
+        encoders._cap_host_threads_once()
+        assert torch.get_num_threads() == usable_cores() + 3          # opted out
+        monkeypatch.setattr(encoders, "_threads_capped", False)
+        monkeypatch.delenv("SAGE_KEEP_TORCH_THREADS")
+        encoders._cap_host_threads_once()
+        assert torch.get_num_threads() == usable_cores()
+        torch.set_num_threads(usable_cores() + 3)
+        encoders._cap_host_threads_once()                              # once per process: a caller's later choice is respected
+        assert torch.get_num_threads() == usable_cores() + 3
+    finally:
+        torch.set_num_threads(before)
+
+
 def test_rmat_accelerated_integer_path_gives_the_same_csr():
     """rmat_graph(accel=...) runs the integer work on torch; the uniforms still come from numpy's stream, so the CSR is identical."""
     a = G.rmat_graph(13, 150_000, seed=3, accel=None, chunk=1 << 16)
