@@ -51,8 +51,6 @@ const sage_tunables_t& sage_tunables() {
         x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);
         x.dense_pc = env_int("SAGE_DENSE_PC", 0, 0, 1);
         x.tile16_waves = env_int("SAGE_T16_WAVES", 8, 8, 16) >= 16 ? 16 : 8;
-        x.sample_inner_grid = env_int("SAGE_SI_GRID", 2048, 0, 65536);
-        x.pipe_pair = env_int("SAGE_PIPE_PAIR", 1, 1, 4);
         return x;
     }();
     return t;

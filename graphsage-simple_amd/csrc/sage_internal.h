@@ -32,13 +32,6 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
                        int nodes_from_batch, int32_t* nodes_copy, int32_t n_off, int32_t frontier_row_off,
                        const sage_resolve_t* resolve, int32_t cursor_off, uint64_t* key_slot, const int32_t* seed_map, hipStream_t st);
 
-// Several batches' hops in ONE launch (sage_sample.hip, sample_multi_kernel): between _begin and _launch every sage_launch_sample call of the
-// calling thread is collected instead of launched (same fanout, list bound and kind of hop for all of them; at most four).
-void sage_sample_collect_begin();
-int sage_sample_collect_count();
-int sage_sample_collect_launch(hipStream_t st);
-void sage_sample_collect_abort();
-
 int sage_launch_sample_fused(const sage_model_t* m, const int32_t* seeds, int32_t batch, uint64_t seed, int32_t* nbr2, int32_t* cnt2,
                              int32_t* any2, const sage_frontier_t* frontier, int32_t insert_self, int32_t* nbr_slot, int32_t* self_slot,
                              int queued, int32_t* nodes_copy, int32_t frontier_row_off, int32_t* nbr1, int32_t* cnt1, int32_t* any1,
@@ -113,9 +106,6 @@ struct sage_tunables_t {
                                   //                      59.7 us per forward; concat 116 vs 91): its block holds 2 x 248 of a SIMD's 512 VGPRs, so nothing
                                   //                      else fits on its CU, where the lock-step kernel's 2 x 168 leave room for the gather's waves
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks, default: 1.5 us per forward in the pipeline)
-    int sample_inner_grid;        // SAGE_SI_GRID         inner-hop sampler: at most this many blocks per batch, walking the worst-case node list in strides
-                                  //                      (0 = one block per chunk of the list's upper bound, the form of rounds 1-3)
-    int pipe_pair;                // SAGE_PIPE_PAIR       role pipeline: stream S serves up to this many batches per sampler launch (1 = one launch per batch and hop)
 };
 // n_words 32-bit words := v, as a kernel (hipMemsetAsync misbehaves inside replayed hipGraphs on ROCm 7.2: sage_api.hip)
 int sage_fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t st);

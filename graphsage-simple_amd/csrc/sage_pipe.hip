@@ -295,42 +295,6 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
     }
 }
 
-// Role S for a GROUP of consecutive batches (VERDICT r3 #1a): both hops of all of them as ONE launch per hop (sample_multi_kernel) --
-// the hops are chains of dependent round trips over 2 MB of ids, so twice the rows cost the chain once, and stream S pays two kernel
-// boundaries per group instead of per batch.  Each batch keeps its own workspace (frontier, counters): bit-identical to role_enqueue(RS)
-// batch by batch.  Eager submission only (never while capturing); not with the one-launch fused sampler (its two stages are one call).
-static int role_enqueue_sample_group(sage_pipe* p, const pipe_desc* const* d, int g) {
-    const sage_model_t* m = &p->model;
-    for (int i = 0; i < g; ++i) {
-        const int slot = d[i]->slot;
-        if (!d[i]->fresh && p->st[RS] != p->st[RL]) {
-            SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset "
-                                               "(after synchronising) before submitting eagerly again");
-            if (int rc = wait_on(p, RS, RL, slot)) return rc;
-        }
-    }
-#ifndef SAGE_PIPE_SKIP_S
-    for (int stage : {SAGE_STAGE_SAMPLE_OUTER, SAGE_STAGE_SAMPLE_INNER}) {
-        sage_sample_collect_begin();
-        for (int i = 0; i < g; ++i)
-            if (int rc = sage_forward2_launch_stages(m, p->ws[d[i]->slot], p->ws_bytes, d[i]->seeds, p->batch, d[i]->key, nullptr, 0, stage, p->st[RS])) {
-                sage_sample_collect_abort();
-                return rc;
-            }
-        if (int rc = sage_sample_collect_launch(p->st[RS])) return rc;
-    }
-#endif
-    for (int i = 0; i < g; ++i)
-        if (int rc = record(p, RS, d[i]->slot, p->st[RG] != p->st[RS] || p->st[RD] != p->st[RS])) return rc;
-    return SAGE_OK;
-}
-// how many batches role S may serve with one launch per hop
-static int pipe_group_limit(const sage_pipe* p) {
-    const sage_tunables_t& t = sage_tunables();
-    if (t.sample_fused || p->st[RS] == p->st[RG]) return 1;
-    return t.pipe_pair < p->depth ? t.pipe_pair : p->depth;
-}
-
 // ---- host enqueue threads ------------------------------------------------------------------------------------------------
 namespace {
 inline void cpu_relax() { __builtin_ia32_pause(); }
@@ -385,7 +349,6 @@ void role_thread(sage_pipe* p, int r) {
         }
         const pipe_desc& d = p->ring[b % kRing];
         // the HOST order HIP's event semantics need: the producer's record for this batch has been made
-        int g = 1;
         if (r == RS) {
             if (!d.fresh && !spin_until(p, [&] { return p->done[RL].load(std::memory_order_acquire) + (uint64_t)p->depth > b; })) return;
             if (p->window > 0 && b >= (uint64_t)p->window) {
@@ -395,32 +358,18 @@ void role_thread(sage_pipe* p, int r) {
                 hipEvent_t e = p->ev_done[(b - (uint64_t)p->window) % kDoneEvents];
                 if (!spin_until(p, [&] { return hipEventQuery(e) != hipErrorNotReady; })) return;
             }
-            // the following batches whose turn it is as well join this one's launches
-            const int limit = pipe_group_limit(p);
-            while (g < limit && p->window == 0 && p->posted.load(std::memory_order_acquire) > b + (uint64_t)g) {
-                const pipe_desc& n = p->ring[(b + (uint64_t)g) % kRing];
-                if (!n.fresh && p->done[RL].load(std::memory_order_acquire) + (uint64_t)p->depth <= b + (uint64_t)g) break;
-                ++g;
-            }
         } else if (!spin_until(p, [&] { return p->done[r - 1].load(std::memory_order_acquire) > b; })) {
             return;
         }
         if (p->worker_rc.load(std::memory_order_relaxed) == 0) {      // after a failure nothing more is enqueued; the counters still advance
-            int rc;
-            if (r == RS && g > 1) {
-                const pipe_desc* grp[SAGE_PIPE_MAX_DEPTH];
-                for (int i = 0; i < g; ++i) grp[i] = &p->ring[(b + (uint64_t)i) % kRing];
-                rc = role_enqueue_sample_group(p, grp, g);
-            } else {
-                rc = role_enqueue(p, r, d, 0);
-            }
+            int rc = role_enqueue(p, r, d, 0);
             if (rc == SAGE_OK && r == RL && p->window > 0 && hipEventRecord(p->ev_done[b % kDoneEvents], p->st[RL]) != hipSuccess) {
                 sage_set_error("pipe: hipEventRecord failed");
                 rc = SAGE_ELAUNCH;
             }
             if (rc != SAGE_OK) worker_fail(p, rc);
         }
-        b += (uint64_t)g;
+        ++b;
         p->done[r].store(b, std::memory_order_release);
     }
 }
@@ -574,36 +523,9 @@ extern "C" int sage_pipe_submit_many(sage_pipe_t* p, const int32_t* seeds, int64
     SAGE_REQUIRE(ldo >= p->model.h2, "pipe_submit_many: ldo = %lld < h2", (long long)ldo);
     SAGE_REQUIRE(out_slots >= p->depth || out_stride == 0, "pipe_submit_many: %d output slots for %d batches in flight", out_slots, p->depth);
     const uint64_t base = segment_start ? p->submitted : 0;
-    auto is_fresh = [&](uint64_t b) { return b - base < (uint64_t)p->depth && (segment_start || b < (uint64_t)p->depth); };
-    // the caller's thread makes every call itself: role S may still serve a group of batches per launch (eager submission only)
-    unsigned long long cap = 0;
-    if (!p->threaded)
-        if (int rc = capture_id(p->st[RS], &cap)) return rc;
-    const int limit = (!p->threaded && cap == 0) ? pipe_group_limit(p) : 1;
-    for (int32_t i = 0; i < n;) {
-        const int g = (n - i) < limit ? (n - i) : limit;
-        if (g == 1) {
-            if (int rc = submit_one(p, seeds + (int64_t)i * seed_stride, keys_host[i], out + (int64_t)(i % out_slots) * out_stride, ldo, is_fresh(p->submitted))) return rc;
-            ++i;
-            continue;
-        }
-        pipe_desc d[SAGE_PIPE_MAX_DEPTH];
-        const pipe_desc* dp[SAGE_PIPE_MAX_DEPTH];
-        for (int j = 0; j < g; ++j) {
-            const uint64_t b = p->submitted + (uint64_t)j;
-            d[j] = pipe_desc{seeds + (int64_t)(i + j) * seed_stride, keys_host[i + j], out + (int64_t)((i + j) % out_slots) * out_stride, ldo,
-                             (int)(b % (uint64_t)p->depth), is_fresh(b), {nullptr, nullptr}};
-            dp[j] = &d[j];
-        }
-        if (int rc = role_enqueue_sample_group(p, dp, g)) return rc;
-        for (int j = 0; j < g; ++j) {
-            for (int r = RG; r <= RL; ++r)
-                if (int rc = role_enqueue(p, r, d[j], 0)) return rc;
-            p->cap_id[d[j].slot] = 0;
-            p->cap_count[d[j].slot] = 0;
-            ++p->submitted;
-        }
-        i += g;
+    for (int32_t i = 0; i < n; ++i) {
+        const bool fresh = p->submitted - base < (uint64_t)p->depth && (segment_start || p->submitted < (uint64_t)p->depth);
+        if (int rc = submit_one(p, seeds + (int64_t)i * seed_stride, keys_host[i], out + (int64_t)(i % out_slots) * out_stride, ldo, fresh)) return rc;
     }
     return SAGE_OK;
 }

@@ -22,36 +22,6 @@ namespace {
 
 using namespace sage_sample_detail;
 
-// One hop's arguments (what sample_kernel used to take as 24 scalars), so that ONE launch can serve several batches (sample_multi_kernel)
-struct SampleArgs {
-    const int64_t* rowptr; const int32_t* col; const int32_t* nodes; int n; const int32_t* n_dev;
-    int k; uint32_t key0, key1, tag; int tag_self_rows; uint32_t tag_self;
-    const int32_t* in_nbr; const int32_t* in_cnt; int32_t* nbr; int32_t* cnt; int32_t* any_nonempty;
-    FrontierDev f; int insert_self; int32_t* nbr_slot; int32_t* self_slot; BatchSrc bs; int n_off; ResolveJob rj;
-};
-
-// Blocks [bid, bid + nblk, ...) of one hop: the launch may be SMALLER than the node list's upper bound (the inner hop's list is
-// sized for the worst-case frontier, 4.5 x what a batch at BASELINE config 3 fills: 6656 blocks of which 1470 find a row; the other
-// 5186 were dispatched, read the row count and left -- 20 k waves per launch queueing for the slots the gather's waves hold).
-// A capped grid walks the list in strides; a block whose first chunk is already past the live rows leaves after the resolve job.
-template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
-__device__ __forceinline__ void sample_strided(const SampleArgs& a, const int bid, const int nblk) {
-    constexpr int GPB = THREADS / G;
-    int nn = a.n;
-    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
-    for (int b = bid;; b += nblk) {
-        sample_block<G, THREADS, SAMPLE, FRONTIER>(a.rowptr, a.col, a.nodes, a.n, a.n_dev, a.k, a.key0, a.key1, a.tag, a.tag_self_rows, a.tag_self,
-                                                   a.in_nbr, a.in_cnt, a.nbr, a.cnt, a.any_nonempty, a.f, a.insert_self, a.nbr_slot, a.self_slot,
-                                                   a.bs, a.n_off, b == bid ? a.rj : ResolveJob{}, b, nblk);
-        if ((int64_t)(b + nblk) * GPB >= (int64_t)nn) break;
-        __syncthreads();                   // the block's LDS scratch (dedupe table, counters, flag) is reused by the next chunk
-    }
-}
-
-// Scalar parameters, not `const SampleArgs a`: with the struct as ONE by-value argument the compiler keeps every field in SGPRs for the
-// kernel's whole life (106 SGPRs, 36-42 VGPRs against 35-62 / 19-21 with scalars, where each instantiation drops the arguments it does not
-// use): fewer blocks per CU, and the inner hop alone went from 12.2 to 16.0 us (round 4, same-box).  The multi-batch kernel below has no
-// choice (its items are picked by blockIdx) and pays that.
 template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
 __global__ __launch_bounds__(THREADS) void sample_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -61,38 +31,8 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
     int32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int32_t* __restrict__ any_nonempty,
     FrontierDev f, int insert_self, int32_t* __restrict__ nbr_slot, int32_t* __restrict__ self_slot, BatchSrc bs,
     int n_off, ResolveJob rj) {
-    constexpr int GPB = THREADS / G;
-    const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
     sample_block<G, THREADS, SAMPLE, FRONTIER>(rowptr, col, nodes, n, n_dev, k, key0, key1, tag, tag_self_rows, tag_self, in_nbr, in_cnt, nbr, cnt,
-                                               any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, rj, bid, nblk);
-#ifndef SAGE_S_NOLOOP      /* A/B build without the strided tail (then only valid with SAGE_SI_GRID=0) */
-    if constexpr (!FRONTIER) {
-        // capped grid (blocks_for): the chunks of the node list past the first pass, if the live rows reach that far
-        if ((int64_t)nblk * GPB < (int64_t)n) {
-            int nn = n;
-            if (n_dev) nn = min(*n_dev + n_off, n);
-            for (int b = bid + nblk; (int64_t)b * GPB < (int64_t)nn; b += nblk) {
-                __syncthreads();               // the block's LDS scratch (flag word) is reused by the next chunk
-                sample_block<G, THREADS, SAMPLE, FRONTIER>(rowptr, col, nodes, n, n_dev, k, key0, key1, tag, tag_self_rows, tag_self, in_nbr, in_cnt,
-                                                           nbr, cnt, any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, ResolveJob{}, b, nblk);
-            }
-        }
-    }
-#endif
-}
-
-// The same hop for up to kSampleMulti BATCHES in one launch (VERDICT r3 #1a): item i's blocks are blockIdx.x % count == i, so the
-// blocks that find rows come first for every item.  The hops are latency-bound (4-6 dependent round trips per node, 2 MB of ids):
-// twice the rows in flight cost the chain once, and stream S pays one kernel boundary per hop and PAIR of batches instead of one per
-// batch.  Every item has a workspace (frontier, counters) of its own: per-call dedupe as aggregators.py:52, results bit-identical
-// to one launch per batch.
-constexpr int kSampleMulti = 4;
-struct SampleMulti { SampleArgs item[kSampleMulti]; int count; };
-
-template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
-__global__ __launch_bounds__(THREADS) void sample_multi_kernel(const SampleMulti m) {
-    const int it = (int)blockIdx.x % m.count;
-    sample_strided<G, THREADS, SAMPLE, FRONTIER>(m.item[it], (int)blockIdx.x / m.count, (int)gridDim.x / m.count);
+                                               any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, rj, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Outer hop + frontier + inner hop in ONE launch, no grid-wide barrier: the inner hop needs no frontier of its own
@@ -157,83 +97,39 @@ int check_frontier(const sage_frontier_t* f, int64_t inserts) {
     return SAGE_OK;
 }
 
-// grid of one item: the whole list, or (no frontier = the inner hop's worst-case list) capped at SAGE_SI_GRID blocks
-template <int G, int THREADS, bool FRONTIER>
-int blocks_for(int n) {
-    const int all = sage_cdiv(n, THREADS / G);
-    if (FRONTIER) return all;
-    const int cap = sage_tunables().sample_inner_grid;
-    return cap > 0 ? min(all, cap) : all;
+template <int G, int THREADS, bool SAMPLE, bool FRONTIER, typename... A>
+void launch_one(int n, hipStream_t st, A... args) {
+    hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(sage_cdiv(n, THREADS / G)), dim3(THREADS), 0, st, args...);
 }
 
-template <int G, int THREADS, bool SAMPLE, bool FRONTIER>
-void launch_one(const SampleMulti& m, hipStream_t st) {
-    const int blocks = blocks_for<G, THREADS, FRONTIER>(m.item[0].n);
-    if (m.count == 1) {
-        const SampleArgs& a = m.item[0];
-        hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(blocks), dim3(THREADS), 0, st, a.rowptr, a.col, a.nodes, a.n, a.n_dev, a.k,
-                           a.key0, a.key1, a.tag, a.tag_self_rows, a.tag_self, a.in_nbr, a.in_cnt, a.nbr, a.cnt, a.any_nonempty, a.f, a.insert_self,
-                           a.nbr_slot, a.self_slot, a.bs, a.n_off, a.rj);
-    } else
-        hipLaunchKernelGGL((sample_multi_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(blocks * m.count), dim3(THREADS), 0, st, m);
+template <int T, bool SAMPLE, bool FRONTIER, typename... A>
+void launch_by_fanout_t(int k, int n, hipStream_t st, A... args) {
+    if (k <= 8) launch_one<8, T, SAMPLE, FRONTIER>(n, st, args...);
+    else if (k <= 16) launch_one<16, T, SAMPLE, FRONTIER>(n, st, args...);
+    else if (k <= 32) launch_one<32, T, SAMPLE, FRONTIER>(n, st, args...);
+    else launch_one<64, T, SAMPLE, FRONTIER>(n, st, args...);
 }
 
-template <int T, bool SAMPLE, bool FRONTIER>
-void launch_by_fanout_t(int k, const SampleMulti& m, hipStream_t st) {
-    if (k <= 8) launch_one<8, T, SAMPLE, FRONTIER>(m, st);
-    else if (k <= 16) launch_one<16, T, SAMPLE, FRONTIER>(m, st);
-    else if (k <= 32) launch_one<32, T, SAMPLE, FRONTIER>(m, st);
-    else launch_one<64, T, SAMPLE, FRONTIER>(m, st);
-}
-
-template <bool SAMPLE, bool FRONTIER>
-void launch_by_fanout(int k, const SampleMulti& m, hipStream_t st) {
+template <bool SAMPLE, bool FRONTIER, typename... A>
+void launch_by_fanout(int k, int n, hipStream_t st, A... args) {
     // frontier variants use 1024-thread blocks: one global counter atomic per 1024/G nodes (256- and 512-thread
     // blocks were measured 3-5 % slower end to end)
     if constexpr (FRONTIER) {
         const int so = sage_tunables().outer_threads;
-        if (so == 256) launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, m, st);
-        else if (so == 512) launch_by_fanout_t<512, SAMPLE, FRONTIER>(k, m, st);
-        else launch_by_fanout_t<1024, SAMPLE, FRONTIER>(k, m, st);
+        if (so == 256) launch_by_fanout_t<256, SAMPLE, FRONTIER>(k, n, st, args...);
+        else if (so == 512) launch_by_fanout_t<512, SAMPLE, FRONTIER>(k, n, st, args...);
+        else launch_by_fanout_t<1024, SAMPLE, FRONTIER>(k, n, st, args...);
     }
 #ifndef SAGE_SI_THREADS
 #define SAGE_SI_THREADS 256
 #endif
-    else launch_by_fanout_t<SAGE_SI_THREADS, SAMPLE, FRONTIER>(k, m, st);
-}
-
-// items of one launch must agree in everything that picks the kernel and its grid
-int launch_items(const SampleMulti& m, bool sample, hipStream_t st) {
-    const SampleArgs& a0 = m.item[0];
-    const bool frontier = a0.f.keys != nullptr;
-    for (int i = 1; i < m.count; ++i) {
-        const SampleArgs& a = m.item[i];
-        SAGE_REQUIRE(a.k == a0.k && a.n == a0.n && (a.f.keys != nullptr) == frontier, "sample (multi): items differ in fanout / list size / frontier");
-    }
-    if (sample && frontier) launch_by_fanout<true, true>(a0.k, m, st);
-    else if (sample) launch_by_fanout<true, false>(a0.k, m, st);
-    else launch_by_fanout<false, true>(a0.k, m, st);
-    SAGE_CHECK_LAUNCH("sample_kernel");
-    return SAGE_OK;
+    else launch_by_fanout_t<SAGE_SI_THREADS, SAMPLE, FRONTIER>(k, n, st, args...);
 }
 
 }  // namespace
 
 // Internal launcher shared with sage_forward.hip (tag_self_rows: rows [0, tag_self_rows)
 // draw from stream `tag_self` -- the concat encoder's second enc1 call on the seeds).
-// Collector (sage_internal.h): while a thread has one open, sage_launch_sample APPENDS its hop instead of launching it
-struct sage_sample_batch { SampleMulti m; bool open; };
-static thread_local sage_sample_batch t_collect{{}, false};
-
-void sage_sample_collect_begin() { t_collect.m.count = 0; t_collect.open = true; }
-int sage_sample_collect_count() { return t_collect.open ? t_collect.m.count : 0; }
-int sage_sample_collect_launch(hipStream_t st) {
-    t_collect.open = false;
-    if (t_collect.m.count == 0) return SAGE_OK;
-    return launch_items(t_collect.m, true, st);
-}
-void sage_sample_collect_abort() { t_collect.open = false; t_collect.m.count = 0; }
-
 int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_nodes, const int32_t* nodes, int32_t n, const int32_t* n_dev,
                        int32_t k, uint64_t seed, uint32_t tag, int32_t tag_self_rows, uint32_t tag_self,
                        int32_t* nbr, int32_t* cnt, int32_t* any_nonempty, const sage_frontier_t* frontier,
@@ -248,20 +144,18 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
     if (resolve) rj = ResolveJob{resolve->slots, resolve->rows_out, resolve->n_slots, resolve->self_slots, resolve->self_rows_out,
                                  resolve->n_self, resolve->hash_rows, resolve->hash_keys};
     FrontierDev fd{};
-    if (frontier)
+    const int32_t* none = nullptr;
+    if (frontier) {
         fd = FrontierDev{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u,
                          frontier->nodes, frontier->count, frontier->max_nodes, frontier_row_off};
-    const SampleArgs a{rowptr, col, nodes, n, n_dev, k, k0, k1, tag, tag_self_rows, tag_self, nullptr, nullptr, nbr, cnt, any_nonempty,
-                       fd, frontier ? insert_self : 0, frontier ? nbr_slot : nullptr, frontier ? self_slot : nullptr, bs, n_off, rj};
-    if (t_collect.open) {
-        SAGE_REQUIRE(t_collect.m.count < kSampleMulti, "sample (multi): more than %d hops collected for one launch", kSampleMulti);
-        t_collect.m.item[t_collect.m.count++] = a;
-        return SAGE_OK;
+        launch_by_fanout<true, true>(k, n, st, rowptr, col, nodes, n, n_dev, k, k0, k1, tag, tag_self_rows, tag_self, none, none,
+                                     nbr, cnt, any_nonempty, fd, insert_self, nbr_slot, self_slot, bs, n_off, rj);
+    } else {
+        launch_by_fanout<true, false>(k, n, st, rowptr, col, nodes, n, n_dev, k, k0, k1, tag, tag_self_rows, tag_self, none, none,
+                                      nbr, cnt, any_nonempty, fd, 0, (int32_t*)nullptr, (int32_t*)nullptr, bs, n_off, rj);
     }
-    SampleMulti m;
-    m.item[0] = a;
-    m.count = 1;
-    return launch_items(m, true, st);
+    SAGE_CHECK_LAUNCH("sample_kernel");
+    return SAGE_OK;
 }
 
 namespace {
@@ -345,9 +239,11 @@ extern "C" int sage_frontier_insert(const int32_t* nbr, const int32_t* cnt, int3
     if (n == 0) return SAGE_OK;
     const FrontierDev fd{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u,
                          frontier->nodes, frontier->count, frontier->max_nodes, 0};
-    SampleMulti m;
-    m.item[0] = SampleArgs{nullptr, nullptr, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt, nullptr, nullptr, nullptr, fd, self_nodes ? 1 : 0,
-                           nbr_slot, self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0}, 0, ResolveJob{}};
-    m.count = 1;
-    return launch_items(m, false, (hipStream_t)stream);
+    const int64_t* no64 = nullptr;
+    const int32_t* no32 = nullptr;
+    launch_by_fanout<false, true>(k, n, (hipStream_t)stream, no64, no32, self_nodes, n, n_dev, k, 0u, 0u, 0u, 0, 0u, nbr, cnt,
+                                  (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, fd, self_nodes ? 1 : 0, nbr_slot,
+                                  self_slot, BatchSrc{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0}, 0, ResolveJob{});
+    SAGE_CHECK_LAUNCH("frontier_insert_kernel");
+    return SAGE_OK;
 }

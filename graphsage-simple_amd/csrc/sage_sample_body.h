@@ -82,15 +82,6 @@ __device__ __forceinline__ void sample_block(
         for (int e = tid; e < LT; e += THREADS) lkeys[e] = -1;
         __syncthreads();
     }
-    // The node id is requested BEFORE the device-side row count is looked at: nodes[] has n entries whatever the count says (rows past
-    // it hold an earlier batch's ids and are masked below), and count -> id -> rowptr -> col was one dependent round trip longer than
-    // id -> rowptr -> col with the count travelling beside the id (the inner hop: 4 trips -> 3).
-    int32_t v_early = -1;
-#ifndef SAGE_S_EARLY
-#define SAGE_S_EARLY 1        /* 0: A/B build without the early request */
-#endif
-    const bool early = SAGE_S_EARLY && SAMPLE && !(bs.queue && bs.nodes_from_batch) && r < n;
-    if (early) v_early = nodes[r];
     int nn = n;
     if (n_dev) nn = min(*n_dev + n_off, n);
     if (rj.slots) {
@@ -132,7 +123,7 @@ __device__ __forceinline__ void sample_block(
     if (SAMPLE) {
         int64_t s = 0, deg = 0;
         if (active) {
-            v = early ? v_early : nodes[r];
+            v = nodes[r];
             if (bs.seed_map) v = ((uint32_t)v < (uint32_t)bs.num_nodes) ? bs.seed_map[v] : -1;
             if (bs.nodes_copy && gl == 0) bs.nodes_copy[r] = v;
             if (wl.seeds && gl == 0) wl.seeds[tid / G] = v;
