@@ -51,6 +51,7 @@ const sage_tunables_t& sage_tunables() {
         x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);
         x.dense_pc = env_int("SAGE_DENSE_PC", 0, 0, 1);
         x.tile16_waves = env_int("SAGE_T16_WAVES", 8, 8, 16) >= 16 ? 16 : 8;
+        { const int r = env_int("SAGE_SI_ROWS", 1, 1, 4); x.sample_inner_rows = r >= 4 ? 4 : r >= 2 ? 2 : 1; }
         return x;
     }();
     return t;
