@@ -51,7 +51,7 @@ const sage_tunables_t& sage_tunables() {
         x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);
         x.dense_pc = env_int("SAGE_DENSE_PC", 0, 0, 1);
         x.tile16_waves = env_int("SAGE_T16_WAVES", 8, 8, 16) >= 16 ? 16 : 8;
-        { const int r = env_int("SAGE_SI_ROWS", 1, 1, 4); x.sample_inner_rows = r >= 4 ? 4 : r >= 2 ? 2 : 1; }
+        x.dense_two = env_int("SAGE_DENSE_TWO", 0, 0, 1);
         return x;
     }();
     return t;
@@ -61,11 +61,18 @@ const sage_tunables_t& sage_tunables() {
 // floats wide to the producer / consumer kernel and back, -1 returns to the SAGE_DENSE_PC default.  Tests run both kernels in one process.
 static std::atomic<int> g_dense_pc_override{-1};       // read by launches on the pipe's role threads
 int sage_dense_pc_enabled() { const int o = g_dense_pc_override.load(std::memory_order_relaxed); return o >= 0 ? o : sage_tunables().dense_pc; }
+static std::atomic<int> g_dense_two_override{-1};
+int sage_dense_two_enabled() { const int o = g_dense_two_override.load(std::memory_order_relaxed); return o >= 0 ? o : sage_tunables().dense_two; }
 extern "C" int sage_set_option(const char* name, int32_t value) {
     SAGE_REQUIRE(name, "set_option: NULL name");
     if (strcmp(name, "dense_pc") == 0) {
         SAGE_REQUIRE(value >= -1 && value <= 1, "set_option: dense_pc = %d outside [-1, 1]", value);
         g_dense_pc_override.store(value, std::memory_order_relaxed);
+        return SAGE_OK;
+    }
+    if (strcmp(name, "dense_two") == 0) {
+        SAGE_REQUIRE(value >= -1 && value <= 1, "set_option: dense_two = %d outside [-1, 1]", value);
+        g_dense_two_override.store(value, std::memory_order_relaxed);
         return SAGE_OK;
     }
     sage_set_error("set_option: unknown option '%s'", name);

@@ -25,6 +25,9 @@ struct DenseArgs {
     float* out; int64_t ldo;
     sage_finish_t fin;
     const uint4* wsplit;      // nullable: W already split into bf16 planes in register order (sage_prepare_weights)
+    // a launch that contracts ONE K chunk of the concat layer (dense_bf16x3_kernel's SRC / EPI forms): the chunk's pass inside the prepared
+    // planes, the number of passes in the buffer (the "W holds a huge value" trailer sits behind them), and the chunk's first W column
+    int wpass, wpasses, woff;
 };
 
 // Concat encoder (K = 2*dim): with KP <= 128 a wave keeps BOTH chunks of its W slice in registers; at KP = 256 the
@@ -261,11 +264,49 @@ __device__ inline bool row_is_huge(const DenseArgs& a, bool concat, int g, bool 
     return h;
 }
 
+// The exact fp32 fma chain of exact_row_dot for ONE K chunk of the concat layer: the nodes' own rows (self, W columns [0, dim), the chain
+// starts at 0 and its partial sum is stored as it is) or the neighbour means (agg, W columns [woff, woff + dim), the chain CONTINUES from
+// the partial sum the self launch left in `out`): over both launches bit for bit the chain over [self | agg].
+__device__ inline float chunk_exact_dot(const DenseArgs& a, bool self_chunk, int g, int col, bool nan_rule) {
+    const float* wrow = a.W + (int64_t)col * a.ldw;
+    if (self_chunk) {
+        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+        const float* sr = a.self_tab + s * a.ld_self;
+        float acc = 0.f;
+        for (int k = 0; k < a.dim; ++k) acc = fmaf(sr[k], wrow[k], acc);
+        return acc;
+    }
+    if (nan_rule && a.cnt[g] == 0) return __builtin_nanf("");
+    float acc = a.out[(int64_t)g * a.ldo + col];
+    const float* xr = a.x + (int64_t)g * a.ldx;
+    for (int k = 0; k < a.dim; ++k) acc = fmaf(xr[k], wrow[a.woff + k], acc);
+    return acc;
+}
+
+__device__ inline bool chunk_row_is_huge(const DenseArgs& a, bool self_chunk, int g, bool nan_rule) {
+    bool h = false;
+    if (self_chunk) {
+        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
+        const float* sr = a.self_tab + s * a.ld_self;
+        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(sr[k]) & 0x7F800000u) >= 0x7F000000u;
+    } else {
+        h = nan_rule && a.cnt[g] == 0;
+        const float* xr = a.x + (int64_t)g * a.ldx;
+        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(xr[k]) & 0x7F800000u) >= 0x7F000000u;
+    }
+    return h;
+}
+
 // MP (KP = 256 only): rows wider than 256 -- every K chunk takes ceil(dim / 256) passes (Pubmed 500, Cora 1433+3 pad).
 // PREP: W arrives as the planes of sage_prepare_weights (a.wsplit; one-pass shapes only) -- a compile-time property, so that no
 // join of two W paths stands between the W loads and their first use.
-template <int KP, bool CONCAT, bool MP, bool PREP = false>
+// SRC / EPI (round 4; CONCAT = false, prepared planes only): ONE K chunk of the 512-deep concat layer per launch, so that the chunk of the
+// nodes' own rows -- which needs the sampling only -- can run BESIDE the gather (role pipeline, SAGE_STAGE_CONTRACT1_SELF) and the means'
+// chunk finishes the layer: SRC 1 = rows come from self_tab through self_index, 0 = from x;  EPI 1 = out := partial sums (no activation),
+// EPI 2 = out := act(out + sums), 0 = out := act(sums).  Compile-time, for the reason PREP is (no join of two paths between a load and its use).
+template <int KP, bool CONCAT, bool MP, bool PREP = false, int SRC = 0, int EPI = 0>
 __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
+    static_assert((SRC == 0 && EPI == 0) || (!CONCAT && !MP && PREP), "chunk launches: non-concat one-pass kernel on prepared planes");
     constexpr int M = 32, WAVES = 8;
     constexpr int CHUNKS = CONCAT ? 2 : 1;
     // The 512-deep concat layer (two 256-wide chunks) is contracted in two K PASSES so that a wave's W slice stays at
@@ -315,7 +356,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         // (Two-pass 512-deep layer only: same-box A/B, concat forward at config 3 86.6 -> 83.7 us.  In the one-pass concat kernel
         // (KP <= 128) the four index registers cross an occupancy step, 167 -> 172 VGPRs, and although the kernel alone gains --
         // 28.8 -> 26.3 us at config 5 -- the pipeline loses: 82.5 -> 86.0 us, three runs each.)
-        constexpr bool SELF_AHEAD = CONCAT && !MP && KP == 256;
+        constexpr bool SELF_AHEAD = (CONCAT && !MP && KP == 256) || SRC == 1;
         int sidx[SELF_AHEAD ? PASSES : 1];
         auto request_self_index = [&](int tile) {
             if constexpr (SELF_AHEAD) {
@@ -333,7 +374,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         auto request_tile = [&](int tile, int pass) {
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc) {
-                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean (block-uniform)
+                const bool is_agg = SRC == 0 && ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean (block-uniform)
                 const int coff = min((pass % ppc) * KP + c0, a.dim - 4);         // this lane's first column of the chunk (dim % 4 == 0)
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
@@ -357,13 +398,24 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     if (!is_agg) request_self_index(tile + stride);       // a block's tiles come in this order in every pass structure but MP
             }
         };
+        // EPI 2: the partial sums the self launch left in `out` for the two rows this thread finishes, requested before the tile's MFMA loop
+        f32x4 prev[M / (WAVES * 2)];
+        auto request_prev = [&](int tile) {
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int it = 0; it < M / (WAVES * 2); ++it) {
+                    const int g = min(tile * M + wave * (M / WAVES) + 2 * it + (lane >> 5), nn - 1);
+                    prev[it] = *reinterpret_cast<const f32x4*>(a.out + (int64_t)g * a.ldo + min((lane & 31) * 4, a.out_dim - 4));
+                }
+            }
+        };
         int stage_seq = 0;                                    // stagings so far (block-uniform): the tag a "huge value" mark carries,
                                                               // so that marks never have to be cleared (a clear would race the next staging)
         auto stage_tile = [&](__bf16* buf, int bsel, int tile, int pass) {   // VGPRs -> mask -> split -> three bf16 LDS planes
             ++stage_seq;
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc) {
-                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;
+                const bool is_agg = SRC == 0 && ((pass / ppc) * PCH + pc) == CHUNKS - 1;
                 const bool col_ok = (pass % ppc) * KP + c0 < a.dim;
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
@@ -401,7 +453,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         if (tid < 96) flags[tid] = 0;                         // ordered before the first staging by the barrier below
         lds_barrier();
         if constexpr (PREP)                                   // sage_prepare_weights left "W holds |w| >= 2^127 / Inf / NaN" behind the planes
-            if (tid == 0 && a.wsplit[(size_t)npass * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
+            if (tid == 0 && a.wsplit[(size_t)(a.wpasses > 0 ? a.wpasses : npass) * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
         STAMP(0);
         request_self_index((int)blockIdx.x);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
@@ -422,7 +474,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     // a third of the kernel, in-kernel s_memtime stamps)
                     // wave-uniform base (SGPR pair) + one lane offset: 24 per-lane 64-bit addresses (the planes span 24 KiB, beyond a
                     // load's immediate offset) cost 48 VGPRs and, in the 512-deep kernel, spills
-                    const uint4* wp = a.wsplit + (size_t)(pass * WAVES + __builtin_amdgcn_readfirstlane(wave)) * STEPS * 3 * 64;
+                    const uint4* wp = a.wsplit + (size_t)((pass + a.wpass) * WAVES + __builtin_amdgcn_readfirstlane(wave)) * STEPS * 3 * 64;
 #pragma unroll
                     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
@@ -490,6 +542,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     }
                     STAMP(stamp_i); ++stamp_i;
                     // the next work item's rows are in flight during the MFMA loop below
+                    request_prev(tile);
                     if (t + 1 < TG && tile + stride < ntiles) request_tile(tile + stride, pass);
                     else if (pass + 1 < npass) request_tile(t0, pass + 1);
                     else if (t0 + TG * stride < ntiles) request_tile(t0 + TG * stride, 0);
@@ -545,12 +598,17 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                         const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (M + row) * PLD + col);
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = sage_activate(p0[e] + p1[e], a.act);
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (EPI == 1) v[e] = p0[e] + p1[e];
+                            else if constexpr (EPI == 2) v[e] = sage_activate(prev[it][e] + (p0[e] + p1[e]), a.act);
+                            else v[e] = sage_activate(p0[e] + p1[e], a.act);
+                        }
                         if (bad[t] & (8 | (2 << it))) continue;    // a row with a huge value (or huge W): redone exactly below; other rows of
                                                                    // the tile keep the MFMA result, so a row never depends on its tile mates
                         float* dst = a.out + (int64_t)g * a.ldo + col;
                         if (col + 3 < a.out_dim && vec_store) {
-                            sage_store_stream<SAGE_H1_STORE>(reinterpret_cast<f32x4*>(dst), v);
+                            if constexpr (EPI == 1) *reinterpret_cast<f32x4*>(dst) = v;          // re-read by the means' launch: not a streaming store
+                            else sage_store_stream<SAGE_H1_STORE>(reinterpret_cast<f32x4*>(dst), v);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -579,7 +637,12 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 const int tile = all ? tb : flags[4 + li];
                 for (int idx = tid; idx < per; idx += (int)blockDim.x) {
                     const int g = tile * M + idx / a.out_dim, col = idx % a.out_dim;
-                    if (g < nn && (flags[2] != 0 || row_is_huge(a, CONCAT, g, nan_rule)))
+                    if constexpr (SRC != 0 || EPI != 0) {
+                        if (g < nn && (flags[2] != 0 || chunk_row_is_huge(a, SRC == 1, g, nan_rule))) {
+                            const float d = chunk_exact_dot(a, SRC == 1, g, col, nan_rule);
+                            a.out[(int64_t)g * a.ldo + col] = EPI == 1 ? d : sage_activate(d, a.act);
+                        }
+                    } else if (g < nn && (flags[2] != 0 || row_is_huge(a, CONCAT, g, nan_rule)))
                         a.out[(int64_t)g * a.ldo + col] = sage_activate(exact_row_dot(a, CONCAT, g, col, nan_rule), a.act);
                 }
             }
@@ -588,7 +651,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-template <int KP, bool CONCAT, bool MP = false, bool PREP = false>
+template <int KP, bool CONCAT, bool MP = false, bool PREP = false, int SRC = 0, int EPI = 0>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     if constexpr (!PREP)
         if (a.wsplit) return launch_bf16x3<KP, CONCAT, MP, true>(a, st);
@@ -596,7 +659,7 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
     static bool configured = false;
     if (!configured) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP, PREP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP, PREP, SRC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess) {
             sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
@@ -608,7 +671,7 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     // and the other batch's latency-bound kernels get the remaining CUs to themselves (same-box A/B: 184-224 blocks
     // 81.3-81.9 us, 256 blocks 84.2, 160 blocks 83.1).
     const int grid = min(sage_cdiv(a.n, 32), sage_tunables().dense_blocks);
-    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP, SRC, EPI>), dim3(grid), dim3(512), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
     return SAGE_OK;
 }
@@ -1069,8 +1132,8 @@ bool sage_layer_dense_supported(int32_t dim, int32_t out_dim) {
 // The 512-deep concat layer as two launches of the producer / consumer kernel (self chunk, then the means' chunk): possible when
 // the prepared planes exist and the output rows can be re-read 16 bytes at a time.
 bool sage_layer_dense_two_launches(int32_t dim, int32_t out_dim, int32_t concat, const void* weight_prepared, const float* out, int64_t ldo) {
-    return sage_dense_pc_enabled() != 0 && concat && weight_prepared && dim > 128 && dim <= 256 && sage_layer_dense_supported(dim, out_dim) &&
-           ldo % 4 == 0 && sage_aligned(out, 16) && out_dim % 4 == 0;
+    return (sage_dense_pc_enabled() != 0 || sage_dense_two_enabled() != 0) && concat && weight_prepared && dim > 128 && dim <= 256 &&
+           sage_layer_dense_supported(dim, out_dim) && ldo % 4 == 0 && sage_aligned(out, 16) && out_dim % 4 == 0;
 }
 
 // parts: SAGE_DENSE_PART_SELF (the self chunk's partial sums -> out), SAGE_DENSE_PART_AGG (out = act(out + means' chunk)), or both
@@ -1121,6 +1184,22 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
             }
             return SAGE_OK;
         }
+    }
+    if (two) {
+        // the lock-step kernel, one K chunk per launch (round 4): the nodes' own rows -> partial sums in `out`, then out = act(out + means' chunk)
+        if (parts & SAGE_DENSE_PART_SELF) {
+            DenseArgs as = a;
+            as.fin = (parts & SAGE_DENSE_PART_AGG) ? sage_finish_t{nullptr, nullptr} : fin;
+            as.cnt = nullptr;                          // the 0/0 rule belongs to the means' chunk
+            as.wpass = 0; as.wpasses = 2; as.woff = 0;
+            if (int rc = launch_bf16x3<256, false, false, true, 1, 1>(as, st)) return rc;
+        }
+        if (parts & SAGE_DENSE_PART_AGG) {
+            DenseArgs ag = a;
+            ag.wpass = 1; ag.wpasses = 2; ag.woff = dim;
+            if (int rc = launch_bf16x3<256, false, false, true, 0, 2>(ag, st)) return rc;
+        }
+        return SAGE_OK;
     }
     if (!concat) {
         if (kp == 64) return launch_bf16x3<64, false>(a, st);

@@ -106,12 +106,14 @@ struct sage_tunables_t {
                                   //                      59.7 us per forward; concat 116 vs 91): its block holds 2 x 248 of a SIMD's 512 VGPRs, so nothing
                                   //                      else fits on its CU, where the lock-step kernel's 2 x 168 leave room for the gather's waves
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks, default: 1.5 us per forward in the pipeline)
-    int sample_inner_rows;        // SAGE_SI_ROWS         inner-hop sampler (fanout <= 16): nodes per 16-lane group, 1 (sample_kernel) / 2 / 4 (sample_inner_rows_kernel)
+    int dense_two;                // SAGE_DENSE_TWO       1: the 512-deep concat contraction as TWO launches of the lock-step kernel (the nodes' own rows' chunk, which
+                                  //                      the role pipeline runs beside the gather, then the means' chunk); 0: one two-pass launch
 };
 // n_words 32-bit words := v, as a kernel (hipMemsetAsync misbehaves inside replayed hipGraphs on ROCm 7.2: sage_api.hip)
 int sage_fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t st);
 const sage_tunables_t& sage_tunables();
 int sage_dense_pc_enabled();          // SAGE_DENSE_PC, or what sage_set_option("dense_pc", ...) last said
+int sage_dense_two_enabled();         // SAGE_DENSE_TWO, or what sage_set_option("dense_two", ...) last said
 
 // Narrowest layer that takes the split form (column-sliced gather + dense contraction) instead of the one-launch layer.
 #ifndef SAGE_SPLIT_MIN_DIM

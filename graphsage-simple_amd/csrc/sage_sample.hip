@@ -35,98 +35,6 @@ __global__ __launch_bounds__(THREADS) void sample_kernel(
                                                any_nonempty, f, insert_self, nbr_slot, self_slot, bs, n_off, rj, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// The inner hop with R NODES PER LANE GROUP (round 4).  In the role pipeline every wave slot of the chip is taken (the five kernels of
-// four batches want ~9600 resident waves, the chip has 8192), and what the latency-bound kernels hold the gather cannot use for loads in
-// flight.  sample_kernel<16, 256, true, false> spends 5900 waves on 23.5 k nodes -- four nodes per wave, each wave sitting through the
-// chain id -> rowptr -> col once.  Here a lane group walks R consecutive rows with the R chains interleaved (R ids requested together,
-// then R row-pointer pairs, then R x k column reads): a quarter of the waves for the same requests in flight.  Same draws: the Philox
-// counter is (node, tag, .), so the sets are those of oracle/sampler_ref.c whatever kernel drew them.
-template <int G, int THREADS, int R>
-__global__ __launch_bounds__(THREADS) void sample_inner_rows_kernel(
-    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ nodes, int n, const int32_t* __restrict__ n_dev,
-    int k, uint32_t key0, uint32_t key1, uint32_t tag, int tag_self_rows, uint32_t tag_self,
-    int32_t* __restrict__ nbr, int32_t* __restrict__ cnt, int32_t* __restrict__ any_nonempty, BatchSrc bs, int n_off, ResolveJob rj) {
-    constexpr int GPB = THREADS / G;
-    const int tid = threadIdx.x, gl = tid & (G - 1), lane = tid & (kWave - 1);
-    const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
-    int nn = n;
-    if (n_dev) nn = min(*n_dev + n_off, n);
-    if (rj.slots) {                                     // the side job of the inner-hop launch (sample_block): hash slots -> frontier rows, keys wiped
-        const int stride = nblk * THREADS;
-        for (int e = bid * THREADS + tid; e < rj.n_slots; e += stride) {
-            const int sl = rj.slots[e];
-            int row = -1;
-            if (sl >= 0) { row = rj.hash_rows[sl]; rj.hash_keys[sl] = -1; }
-            rj.rows_out[e] = row;
-        }
-        if (rj.self_slots) {
-            for (int e = bid * THREADS + tid; e < rj.n_self; e += stride) {
-                const int sl = rj.self_slots[e];
-                int row = -1;
-                if (sl >= 0) { row = rj.hash_rows[sl]; rj.hash_keys[sl] = -1; }
-                rj.self_rows_out[e] = row;
-            }
-        }
-    }
-    if (bs.queue) {                                     // graph replay: the sampler key comes from the key slot / the queue descriptor
-        if (bs.key_slot) {
-            const uint64_t kq = *bs.key_slot;
-            key0 = (uint32_t)kq;
-            key1 = (uint32_t)(kq >> 32);
-        } else {
-            const sage_batch_t b = bs.queue[(uint32_t)(*bs.cursor + bs.cursor_off) % (uint32_t)bs.len];
-            key0 = (uint32_t)b.seed;
-            key1 = (uint32_t)(b.seed >> 32);
-        }
-    }
-    const int r0 = (bid * GPB + tid / G) * R;
-    int32_t v[R];
-    int64_t s[R], deg[R];
-    bool act[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        act[j] = r0 + j < nn;
-        v[j] = act[j] ? nodes[r0 + j] : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        s[j] = 0;
-        deg[j] = 0;
-        if (act[j] && (bs.num_nodes == 0 || (uint32_t)v[j] < (uint32_t)bs.num_nodes)) {
-            s[j] = rowptr[v[j]];
-            deg[j] = rowptr[v[j] + 1] - s[j];
-        }
-    }
-    uint32_t pos[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-        pos[j] = sage_group_positions<G>(act[j] && deg[j] > (int64_t)k, deg[j], k, v[j], (r0 + j < tag_self_rows) ? tag_self : tag, key0, key1, gl, lane);
-    int32_t id[R];
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int c = (int)min(deg[j], (int64_t)k);
-        id[j] = -1;
-        if (act[j] && gl < c) id[j] = __builtin_nontemporal_load(col + s[j] + (int64_t)pos[j]);
-        any |= c > 0;
-    }
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-        if (act[j]) {
-            if (gl < k) nbr[(int64_t)(r0 + j) * k + gl] = id[j];
-            if (gl == 0) cnt[r0 + j] = (int)min(deg[j], (int64_t)k);
-        }
-    if (any_nonempty) {                                 // one flag word per launch, touched by one thread per block (see sample_block)
-        __shared__ int blk_any;
-        if (tid == 0) blk_any = 0;
-        __syncthreads();
-        if (__any(any) && lane == 0) blk_any = 1;
-        __syncthreads();
-        if (tid == 0 && blk_any && *any_nonempty == 0) *any_nonempty = 1;
-    }
-}
-
 // Outer hop + frontier + inner hop in ONE launch, no grid-wide barrier: the inner hop needs no frontier of its own
 // (layer-1 neighbour sets are not deduplicated, aggregators.py:52 works per call), only the ROW its node got, and a block
 // knows the rows of the ids it was first to insert as soon as its own counter add returns.  So each block samples the
@@ -237,20 +145,6 @@ int sage_launch_sample(const int64_t* rowptr, const int32_t* col, int64_t num_no
                                  resolve->n_self, resolve->hash_rows, resolve->hash_keys};
     FrontierDev fd{};
     const int32_t* none = nullptr;
-    const int rows_per_group = sage_tunables().sample_inner_rows;
-    if (!frontier && rows_per_group > 1 && k <= 16 && !(qm && nodes_from_batch) && !nodes_copy && !seed_map) {
-        // the inner hop, R nodes per lane group (sample_inner_rows_kernel)
-        constexpr int T = 256, G = 16;
-        if (rows_per_group >= 4) {
-            hipLaunchKernelGGL((sample_inner_rows_kernel<G, T, 4>), dim3(sage_cdiv(n, (T / G) * 4)), dim3(T), 0, st, rowptr, col, nodes, n, n_dev, k, k0, k1, tag,
-                               tag_self_rows, tag_self, nbr, cnt, any_nonempty, bs, n_off, rj);
-        } else {
-            hipLaunchKernelGGL((sample_inner_rows_kernel<G, T, 2>), dim3(sage_cdiv(n, (T / G) * 2)), dim3(T), 0, st, rowptr, col, nodes, n, n_dev, k, k0, k1, tag,
-                               tag_self_rows, tag_self, nbr, cnt, any_nonempty, bs, n_off, rj);
-        }
-        SAGE_CHECK_LAUNCH("sample_inner_rows_kernel");
-        return SAGE_OK;
-    }
     if (frontier) {
         fd = FrontierDev{frontier->keys, frontier->rows, (uint32_t)frontier->capacity - 1u,
                          frontier->nodes, frontier->count, frontier->max_nodes, frontier_row_off};
