@@ -22,11 +22,21 @@ phases = [[rows[0]]]; last = rows[0][1]
 for r in rows[1:]:
     if r[0] - last > 300_000: phases.append([])
     phases[-1].append(r); last = max(last, r[1])
-p = max(phases, key=len) if len(sys.argv) <= 4 else phases[int(sys.argv[4])]
+# the timed region + its warm-up: the LAST phase that holds 100 .. 1000 forwards (the preheat phases hold thousands, the profiled passes follow it)
+want = int(sys.argv[4]) if len(sys.argv) > 4 else None
+cands = [ph for ph in phases if 100 * 5 <= len(ph) <= 1000 * 5]
+p = phases[want] if want is not None else (cands[0] if cands else max(phases, key=len))
+print("phases (kernels): " + " ".join(str(len(ph)) for ph in phases if len(ph) >= 50))
 by = collections.defaultdict(list)
 for s, e, k in p: by[k].append((s, e))
 n = min(len(v) for v in by.values())
+assert all(len(v) == n for v in by.values()), {k: len(v) for k, v in by.items()}
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else n // 3
+import os
+with open(os.path.join(sys.argv[1], "timed_phase.csv"), "w") as fh:          # small enough to keep: the analysed phase only
+    fh.write("start_ns,end_ns,kind\n")
+    t00 = p[0][0]
+    for s, e, k in p: fh.write(f"{s - t00},{e - t00},{k}\n")
 print(f"{len(phases)} phases; analysed phase: {n} batches, statistics over batches {skip} .. {n - depth - 1}")
 S = {k: np.array(by[k][:n], dtype=np.float64) / 1e3 for k in by}           # us
 def stat(x): x = np.asarray(x); return "avg %5.1f med %5.1f p90 %5.1f" % (x.mean(), np.median(x), np.percentile(x, 90))

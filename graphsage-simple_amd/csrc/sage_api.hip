@@ -49,34 +49,10 @@ const sage_tunables_t& sage_tunables() {
         x.outer_threads = so >= 1024 ? 1024 : so >= 512 ? 512 : 256;
         x.tile16_grid = env_int("SAGE_T16_GRID", 2 * kNumCU, 64, 1024);
         x.sample_fused = env_int("SAGE_SAMPLE_FUSED", 0, 0, 1);
-        x.dense_pc = env_int("SAGE_DENSE_PC", 0, 0, 1);
         x.tile16_waves = env_int("SAGE_T16_WAVES", 8, 8, 16) >= 16 ? 16 : 8;
-        x.dense_two = env_int("SAGE_DENSE_TWO", 0, 0, 1);
         return x;
     }();
     return t;
-}
-
-// Run-time options (the launch tunables above are read once per process): "dense_pc" -- 1 / 0 switches the contraction of rows <= 256
-// floats wide to the producer / consumer kernel and back, -1 returns to the SAGE_DENSE_PC default.  Tests run both kernels in one process.
-static std::atomic<int> g_dense_pc_override{-1};       // read by launches on the pipe's role threads
-int sage_dense_pc_enabled() { const int o = g_dense_pc_override.load(std::memory_order_relaxed); return o >= 0 ? o : sage_tunables().dense_pc; }
-static std::atomic<int> g_dense_two_override{-1};
-int sage_dense_two_enabled() { const int o = g_dense_two_override.load(std::memory_order_relaxed); return o >= 0 ? o : sage_tunables().dense_two; }
-extern "C" int sage_set_option(const char* name, int32_t value) {
-    SAGE_REQUIRE(name, "set_option: NULL name");
-    if (strcmp(name, "dense_pc") == 0) {
-        SAGE_REQUIRE(value >= -1 && value <= 1, "set_option: dense_pc = %d outside [-1, 1]", value);
-        g_dense_pc_override.store(value, std::memory_order_relaxed);
-        return SAGE_OK;
-    }
-    if (strcmp(name, "dense_two") == 0) {
-        SAGE_REQUIRE(value >= -1 && value <= 1, "set_option: dense_two = %d outside [-1, 1]", value);
-        g_dense_two_override.store(value, std::memory_order_relaxed);
-        return SAGE_OK;
-    }
-    sage_set_error("set_option: unknown option '%s'", name);
-    return SAGE_EINVAL;
 }
 
 // Device memory fills as a KERNEL, never as hipMemsetAsync: on ROCm 7.2 a small hipMemsetAsync captured into a hipGraph does what it

@@ -25,9 +25,6 @@ struct DenseArgs {
     float* out; int64_t ldo;
     sage_finish_t fin;
     const uint4* wsplit;      // nullable: W already split into bf16 planes in register order (sage_prepare_weights)
-    // a launch that contracts ONE K chunk of the concat layer (dense_bf16x3_kernel's SRC / EPI forms): the chunk's pass inside the prepared
-    // planes, the number of passes in the buffer (the "W holds a huge value" trailer sits behind them), and the chunk's first W column
-    int wpass, wpasses, woff;
 };
 
 // Concat encoder (K = 2*dim): with KP <= 128 a wave keeps BOTH chunks of its W slice in registers; at KP = 256 the
@@ -264,49 +261,11 @@ __device__ inline bool row_is_huge(const DenseArgs& a, bool concat, int g, bool 
     return h;
 }
 
-// The exact fp32 fma chain of exact_row_dot for ONE K chunk of the concat layer: the nodes' own rows (self, W columns [0, dim), the chain
-// starts at 0 and its partial sum is stored as it is) or the neighbour means (agg, W columns [woff, woff + dim), the chain CONTINUES from
-// the partial sum the self launch left in `out`): over both launches bit for bit the chain over [self | agg].
-__device__ inline float chunk_exact_dot(const DenseArgs& a, bool self_chunk, int g, int col, bool nan_rule) {
-    const float* wrow = a.W + (int64_t)col * a.ldw;
-    if (self_chunk) {
-        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
-        const float* sr = a.self_tab + s * a.ld_self;
-        float acc = 0.f;
-        for (int k = 0; k < a.dim; ++k) acc = fmaf(sr[k], wrow[k], acc);
-        return acc;
-    }
-    if (nan_rule && a.cnt[g] == 0) return __builtin_nanf("");
-    float acc = a.out[(int64_t)g * a.ldo + col];
-    const float* xr = a.x + (int64_t)g * a.ldx;
-    for (int k = 0; k < a.dim; ++k) acc = fmaf(xr[k], wrow[a.woff + k], acc);
-    return acc;
-}
-
-__device__ inline bool chunk_row_is_huge(const DenseArgs& a, bool self_chunk, int g, bool nan_rule) {
-    bool h = false;
-    if (self_chunk) {
-        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
-        const float* sr = a.self_tab + s * a.ld_self;
-        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(sr[k]) & 0x7F800000u) >= 0x7F000000u;
-    } else {
-        h = nan_rule && a.cnt[g] == 0;
-        const float* xr = a.x + (int64_t)g * a.ldx;
-        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(xr[k]) & 0x7F800000u) >= 0x7F000000u;
-    }
-    return h;
-}
-
 // MP (KP = 256 only): rows wider than 256 -- every K chunk takes ceil(dim / 256) passes (Pubmed 500, Cora 1433+3 pad).
 // PREP: W arrives as the planes of sage_prepare_weights (a.wsplit; one-pass shapes only) -- a compile-time property, so that no
 // join of two W paths stands between the W loads and their first use.
-// SRC / EPI (round 4; CONCAT = false, prepared planes only): ONE K chunk of the 512-deep concat layer per launch, so that the chunk of the
-// nodes' own rows -- which needs the sampling only -- can run BESIDE the gather (role pipeline, SAGE_STAGE_CONTRACT1_SELF) and the means'
-// chunk finishes the layer: SRC 1 = rows come from self_tab through self_index, 0 = from x;  EPI 1 = out := partial sums (no activation),
-// EPI 2 = out := act(out + sums), 0 = out := act(sums).  Compile-time, for the reason PREP is (no join of two paths between a load and its use).
-template <int KP, bool CONCAT, bool MP, bool PREP = false, int SRC = 0, int EPI = 0>
+template <int KP, bool CONCAT, bool MP, bool PREP = false>
 __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
-    static_assert((SRC == 0 && EPI == 0) || (!CONCAT && !MP && PREP), "chunk launches: non-concat one-pass kernel on prepared planes");
     constexpr int M = 32, WAVES = 8;
     constexpr int CHUNKS = CONCAT ? 2 : 1;
     // The 512-deep concat layer (two 256-wide chunks) is contracted in two K PASSES so that a wave's W slice stays at
@@ -356,7 +315,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         // (Two-pass 512-deep layer only: same-box A/B, concat forward at config 3 86.6 -> 83.7 us.  In the one-pass concat kernel
         // (KP <= 128) the four index registers cross an occupancy step, 167 -> 172 VGPRs, and although the kernel alone gains --
         // 28.8 -> 26.3 us at config 5 -- the pipeline loses: 82.5 -> 86.0 us, three runs each.)
-        constexpr bool SELF_AHEAD = (CONCAT && !MP && KP == 256) || SRC == 1;
+        constexpr bool SELF_AHEAD = CONCAT && !MP && KP == 256;
         int sidx[SELF_AHEAD ? PASSES : 1];
         auto request_self_index = [&](int tile) {
             if constexpr (SELF_AHEAD) {
@@ -374,7 +333,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         auto request_tile = [&](int tile, int pass) {
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc) {
-                const bool is_agg = SRC == 0 && ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean (block-uniform)
+                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;      // the last K chunk is the neighbour mean (block-uniform)
                 const int coff = min((pass % ppc) * KP + c0, a.dim - 4);         // this lane's first column of the chunk (dim % 4 == 0)
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
@@ -398,24 +357,13 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     if (!is_agg) request_self_index(tile + stride);       // a block's tiles come in this order in every pass structure but MP
             }
         };
-        // EPI 2: the partial sums the self launch left in `out` for the two rows this thread finishes, requested before the tile's MFMA loop
-        f32x4 prev[M / (WAVES * 2)];
-        auto request_prev = [&](int tile) {
-            if constexpr (EPI == 2) {
-#pragma unroll
-                for (int it = 0; it < M / (WAVES * 2); ++it) {
-                    const int g = min(tile * M + wave * (M / WAVES) + 2 * it + (lane >> 5), nn - 1);
-                    prev[it] = *reinterpret_cast<const f32x4*>(a.out + (int64_t)g * a.ldo + min((lane & 31) * 4, a.out_dim - 4));
-                }
-            }
-        };
         int stage_seq = 0;                                    // stagings so far (block-uniform): the tag a "huge value" mark carries,
                                                               // so that marks never have to be cleared (a clear would race the next staging)
         auto stage_tile = [&](__bf16* buf, int bsel, int tile, int pass) {   // VGPRs -> mask -> split -> three bf16 LDS planes
             ++stage_seq;
 #pragma unroll
             for (int pc = 0; pc < PCH; ++pc) {
-                const bool is_agg = SRC == 0 && ((pass / ppc) * PCH + pc) == CHUNKS - 1;
+                const bool is_agg = ((pass / ppc) * PCH + pc) == CHUNKS - 1;
                 const bool col_ok = (pass % ppc) * KP + c0 < a.dim;
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) {
@@ -453,7 +401,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
         if (tid < 96) flags[tid] = 0;                         // ordered before the first staging by the barrier below
         lds_barrier();
         if constexpr (PREP)                                   // sage_prepare_weights left "W holds |w| >= 2^127 / Inf / NaN" behind the planes
-            if (tid == 0 && a.wsplit[(size_t)(a.wpasses > 0 ? a.wpasses : npass) * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
+            if (tid == 0 && a.wsplit[(size_t)npass * WAVES * STEPS * 3 * 64].x != 0) flags[2] = 1;   // read after the first staging's barrier
         STAMP(0);
         request_self_index((int)blockIdx.x);
         request_tile((int)blockIdx.x, 0);                     // the first tile's rows travel while W is fetched and split
@@ -474,7 +422,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     // a third of the kernel, in-kernel s_memtime stamps)
                     // wave-uniform base (SGPR pair) + one lane offset: 24 per-lane 64-bit addresses (the planes span 24 KiB, beyond a
                     // load's immediate offset) cost 48 VGPRs and, in the 512-deep kernel, spills
-                    const uint4* wp = a.wsplit + (size_t)((pass + a.wpass) * WAVES + __builtin_amdgcn_readfirstlane(wave)) * STEPS * 3 * 64;
+                    const uint4* wp = a.wsplit + (size_t)(pass * WAVES + __builtin_amdgcn_readfirstlane(wave)) * STEPS * 3 * 64;
 #pragma unroll
                     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
@@ -542,7 +490,6 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                     }
                     STAMP(stamp_i); ++stamp_i;
                     // the next work item's rows are in flight during the MFMA loop below
-                    request_prev(tile);
                     if (t + 1 < TG && tile + stride < ntiles) request_tile(tile + stride, pass);
                     else if (pass + 1 < npass) request_tile(t0, pass + 1);
                     else if (t0 + TG * stride < ntiles) request_tile(t0 + TG * stride, 0);
@@ -598,17 +545,12 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                         const f32x4 p1 = *reinterpret_cast<const f32x4*>(part + (M + row) * PLD + col);
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if constexpr (EPI == 1) v[e] = p0[e] + p1[e];
-                            else if constexpr (EPI == 2) v[e] = sage_activate(prev[it][e] + (p0[e] + p1[e]), a.act);
-                            else v[e] = sage_activate(p0[e] + p1[e], a.act);
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = sage_activate(p0[e] + p1[e], a.act);
                         if (bad[t] & (8 | (2 << it))) continue;    // a row with a huge value (or huge W): redone exactly below; other rows of
                                                                    // the tile keep the MFMA result, so a row never depends on its tile mates
                         float* dst = a.out + (int64_t)g * a.ldo + col;
                         if (col + 3 < a.out_dim && vec_store) {
-                            if constexpr (EPI == 1) *reinterpret_cast<f32x4*>(dst) = v;          // re-read by the means' launch: not a streaming store
-                            else sage_store_stream<SAGE_H1_STORE>(reinterpret_cast<f32x4*>(dst), v);
+                            sage_store_stream<SAGE_H1_STORE>(reinterpret_cast<f32x4*>(dst), v);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -637,12 +579,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                 const int tile = all ? tb : flags[4 + li];
                 for (int idx = tid; idx < per; idx += (int)blockDim.x) {
                     const int g = tile * M + idx / a.out_dim, col = idx % a.out_dim;
-                    if constexpr (SRC != 0 || EPI != 0) {
-                        if (g < nn && (flags[2] != 0 || chunk_row_is_huge(a, SRC == 1, g, nan_rule))) {
-                            const float d = chunk_exact_dot(a, SRC == 1, g, col, nan_rule);
-                            a.out[(int64_t)g * a.ldo + col] = EPI == 1 ? d : sage_activate(d, a.act);
-                        }
-                    } else if (g < nn && (flags[2] != 0 || row_is_huge(a, CONCAT, g, nan_rule)))
+                    if (g < nn && (flags[2] != 0 || row_is_huge(a, CONCAT, g, nan_rule)))
                         a.out[(int64_t)g * a.ldo + col] = sage_activate(exact_row_dot(a, CONCAT, g, col, nan_rule), a.act);
                 }
             }
@@ -651,7 +588,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
     sage_finish_block(a.fin, (int)gridDim.x);
 }
 
-template <int KP, bool CONCAT, bool MP = false, bool PREP = false, int SRC = 0, int EPI = 0>
+template <int KP, bool CONCAT, bool MP = false, bool PREP = false>
 int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     if constexpr (!PREP)
         if (a.wsplit) return launch_bf16x3<KP, CONCAT, MP, true>(a, st);
@@ -659,7 +596,7 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
     static bool configured = false;
     if (!configured) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP, PREP, SRC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP, PREP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess) {
             sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
@@ -671,366 +608,8 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
     // and the other batch's latency-bound kernels get the remaining CUs to themselves (same-box A/B: 184-224 blocks
     // 81.3-81.9 us, 256 blocks 84.2, 160 blocks 83.1).
     const int grid = min(sage_cdiv(a.n, 32), sage_tunables().dense_blocks);
-    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP, SRC, EPI>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP>), dim3(grid), dim3(512), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
-    return SAGE_OK;
-}
-
-// ---- the same contraction with PRODUCER and CONSUMER waves (round 3) --------------------------------------------------------------
-// dense_bf16x3_kernel runs its eight waves in lock step: everybody stages a tile (global -> split -> LDS), barrier, everybody
-// issues MFMAs, barrier, everybody runs the epilogue.  In-kernel stamps (round 2): of a tile's 8.1 k cycles the matrix pipes work
-// 2.5-3 k; they idle during staging (2.3 k) and the epilogue (3.2 k).  Here the eight waves of a 512-thread block have ROLES, one
-// wave of each role per SIMD:
-//   waves 0-3   CONSUMERS: wave w keeps the W slice of output columns [32 w, +32) over the WHOLE K range (<= 256: up to 192 VGPRs of
-//               prepared planes) and does nothing but ds_read_b128 + v_mfma_f32_32x32x16_bf16 on the tile the producers staged one
-//               phase earlier (one accumulation chain of 6 * K / 16 MFMAs: no K halves to add); its 32 x 32 sums go to a [32][128]
-//               fp32 plane in LDS;
-//   waves 4-7   PRODUCERS: split tile p (its rows were requested one phase ago) into the three bf16 planes of the other LDS buffer,
-//               request the rows of tile p + 1, and finish tile p - 2: read the result plane row-wise, (add the partial sums of an
-//               earlier K chunk,) activate, store 512-B rows.
-// ONE barrier per tile; per phase a SIMD's matrix pipe has 6 * K / 16 MFMAs (3072 cycles at K = 256) of work and the producer's
-// vector instructions ride in the 24 of every 32 cycles in which an MFMA leaves the vector issue free (MI355X_MICROARCH.md).
-// (First form, measured and replaced: twelve waves, eight consumers that each kept one K HALF in 96 VGPRs and ADDED their sums into the
-// plane with ds_add_f32 -- an LDS float atomic costs ~200 cycles per wave-instruction and blocks the LDS pipe for everybody: 128 of
-// them per tile made a phase 27 k cycles, in-kernel stamps of experiments/r03/pc_stamps.py.)
-// The 512-deep concat layer (2 x 256 columns do not fit the register file) is TWO launches of this kernel instead of two passes that
-// reload W per group of tiles: `self` chunk -> partial sums into `out` (epi 1; it depends on the sampling only and runs beside
-// the gather), then `agg` chunk with out = act(out + acc) (epi 2): every block keeps ONE W slice for its whole life.
-#ifdef SAGE_DENSE_STAMPS
-#define STAMP_T(t, i) do { if (threadIdx.x == (t) && (i) < 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_dense_stamps[blockIdx.x * 40 + (i)] = t_; } } while (0)
-#else
-#define STAMP_T(t, i) do { } while (0)
-#endif
-struct PcMode {
-    int src;        // PCH == 1: 0 = the means (a.x), 1 = the nodes' own rows (a.self_tab through a.self_index); PCH == 2: both
-    int epi;        // 0: out = act(acc)    1: out = acc (partial sums of a K chunk)    2: out = act(out + acc)
-    int wpass;      // the pass of the prepared planes this launch contracts
-    int wpasses;    // passes in the prepared buffer (the "W holds a huge value" trailer sits behind them)
-    int agg_woff;   // first W column of the means' chunk (exact cold path): a.dim with a self chunk in front, else 0
-};
-
-// the exact fp32 fma chain of exact_row_dot, restricted to the chunk(s) this launch contracts and continuing from the partial sum
-// an earlier launch left in `out` (epi 2): bit for bit the chain over [self | agg]
-__device__ inline float pc_exact_dot(const DenseArgs& a, const PcMode& md, bool use_self, bool use_agg, int g, int col, bool nan_rule) {
-    const float* wrow = a.W + (int64_t)col * a.ldw;
-    float acc = md.epi == 2 ? a.out[(int64_t)g * a.ldo + col] : 0.f;
-    if (use_self) {
-        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
-        const float* sr = a.self_tab + s * a.ld_self;
-        for (int k = 0; k < a.dim; ++k) acc = fmaf(sr[k], wrow[k], acc);
-    }
-    if (use_agg) {
-        if (nan_rule && a.cnt[g] == 0) return __builtin_nanf("");
-        const float* xr = a.x + (int64_t)g * a.ldx;
-        for (int k = 0; k < a.dim; ++k) acc = fmaf(xr[k], wrow[md.agg_woff + k], acc);
-    }
-    return acc;
-}
-
-__device__ inline bool pc_row_is_huge(const DenseArgs& a, bool use_self, bool use_agg, int g, bool nan_rule) {
-    bool h = false;
-    if (use_agg) {
-        h = nan_rule && a.cnt[g] == 0;
-        const float* xr = a.x + (int64_t)g * a.ldx;
-        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(xr[k]) & 0x7F800000u) >= 0x7F000000u;
-    }
-    if (use_self) {
-        const int64_t s = a.self_index ? (int64_t)min(max(a.self_index[g], 0), a.self_rows - 1) : (int64_t)min(g, a.self_rows - 1);
-        const float* sr = a.self_tab + s * a.ld_self;
-        for (int k = 0; k < a.dim; ++k) h |= (__float_as_uint(sr[k]) & 0x7F800000u) >= 0x7F000000u;
-    }
-    return h;
-}
-
-// SRC and EPI are md.src / md.epi as COMPILE-TIME values: a uniform run-time branch around a load is still a branch, and at its join the
-// compiler waits for every load in flight (s_waitcnt vmcnt(0) in front of each of a tile's eight row requests: 8 k cycles per phase,
-// in-kernel stamps).  For the same reason the optional index / count loads below are unconditional loads from a harmless address.
-template <int KP, int PCH, int SRC, int EPI>
-__global__ __launch_bounds__(512) void dense_pc_kernel(const DenseArgs a, const PcMode md) {
-    constexpr int M = 32, PW = 4;                        // rows per tile, producer waves
-    constexpr int KPASS = PCH * KP, KH = KPASS / 2, STEPS = KH / 16;     // STEPS: k-steps of one K half (the prepared planes' unit)
-    constexpr int LDB = KPASS + 8, PL = M * LDB;         // bf16 elements per LDS row (+16 B) and per plane
-    constexpr int PLD = 128 + 8;                         // floats per row of the result plane
-    constexpr int LG = KP / 4, RPP = 64 / LG, RPW = M / PW, PASSES = RPW / RPP;
-    constexpr int kListCap = 28;
-    static_assert(KPASS <= 256 && KH % 16 == 0 && RPW % RPP == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __bf16* planes = reinterpret_cast<__bf16*>(lds_raw);                                           // [2][3][M][LDB]
-    float* part = reinterpret_cast<float*>(lds_raw + (size_t)2 * 3 * PL * sizeof(__bf16));         // [2][M][PLD]
-    int* flags = reinterpret_cast<int*>(part + 2 * M * PLD);   // [0]: W holds a huge value; [1]: tiles to redo exactly; [2 ..]: their indices
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int nn = a.n;
-    if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
-    const int ntiles = (nn + M - 1) / M;
-    const int stride = (int)gridDim.x;
-    constexpr bool use_self = PCH == 2 || SRC == 1, use_agg = PCH == 2 || SRC == 0;
-    const bool nan_rule = (use_agg && a.cnt && a.any_nonempty) ? (*a.any_nonempty != 0) : false;
-    if ((int)blockIdx.x < ntiles) {
-        const int nt = (ntiles - 1 - (int)blockIdx.x) / stride + 1;      // this block's tiles: blockIdx.x + j * stride, j < nt
-        if (tid == 0) { flags[0] = 0; flags[1] = 0; }
-        STAMP_T(0, 0);
-        STAMP_T(256, 20);
-        lds_barrier();
-        if (wave < 4) {
-            // ------------------------------------------------------------------ consumer: output columns [32 wave, +32), the whole K range
-            const int i32 = lane & 31, h = lane >> 5;
-            const int n0 = wave * 32;
-            const bool mfma_wave = n0 < a.out_dim;
-            bf16x8 bw[2 * STEPS][3];                      // the planes of both K halves (prepared per half: "waves" w and w + 4 of the lock-step kernel)
-            {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const uint4* wp = a.wsplit + (size_t)(md.wpass * 8 + half * 4 + wave) * STEPS * 3 * 64;
-#pragma unroll
-                    for (int st = 0; st < STEPS; ++st)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) bw[half * STEPS + st][pl] = __builtin_bit_cast(bf16x8, wp[(st * 3 + pl) * 64 + lane]);
-                }
-            }
-            if (tid == 0 && a.wsplit[(size_t)md.wpasses * 8 * STEPS * 3 * 64].x != 0) flags[0] = 1;
-            STAMP_T(0, 1);
-            lds_barrier();                                            // phase 0: the producers staged tile 0
-            STAMP_T(0, 2);
-            for (int j = 0; j < nt; ++j) {
-                const __bf16* buf = planes + (j & 1) * 3 * PL;
-                if (mfma_wave) {
-                    // Two accumulators, one per K half, added at the end: the sums (and their rounding) of the lock-step kernel, whose two
-                    // wave groups own a K half each -- bit for bit the same result, and half the length of an accumulation chain.
-                    // A operands one k-step ahead of their MFMAs and no further: left alone the scheduler hoists every ds_read_b128 to the
-                    // top (6 * STEPS * 4 VGPRs on top of the 192 of W).
-                    f32x16 acc[2];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-                    const __bf16* abase = buf + i32 * LDB + 8 * h;
-                    bf16x8 av[2][3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) av[0][pl] = *reinterpret_cast<const bf16x8*>(abase + pl * PL);
-#pragma unroll
-                    for (int st = 0; st < 2 * STEPS; ++st) {
-                        if (st + 1 < 2 * STEPS) {
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) av[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(abase + pl * PL + 16 * (st + 1));
-                        }
-                        const bf16x8 ah = av[st & 1][0], am = av[st & 1][1], al = av[st & 1][2];
-                        f32x16& ac = acc[st / STEPS];
-#ifdef PC_NO_MFMA
-                        ac[0] += (float)ah[0] + (float)am[0] + (float)al[0];
-                        continue;
-#endif
-                        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bw[st][0], ac, 0, 0, 0);
-                        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][2], ac, 0, 0, 0);
-                        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][1], ac, 0, 0, 0);
-                        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bw[st][0], ac, 0, 0, 0);
-                        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][1], ac, 0, 0, 0);
-                        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bw[st][0], ac, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    float* mine = part + (size_t)(j & 1) * M * PLD + n0 + i32;
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) mine[((reg & 3) + 8 * (reg >> 2) + 4 * h) * PLD] = acc[0][reg] + acc[1][reg];
-                }
-                STAMP_T(0, 3 + 2 * j);
-                lds_barrier();
-                STAMP_T(0, 4 + 2 * j);
-            }
-        } else {
-            // ------------------------------------------------------------------ producer
-#ifdef PC_PRIO
-            __builtin_amdgcn_s_setprio(PC_PRIO);
-#endif
-            const int pw = wave - 4;
-            const int lg = lane & (LG - 1), sg = lane / LG;
-            const int c0 = lg * 4;
-            const bool col_ok = c0 < a.dim;
-            const int coff = min(c0, a.dim - 4);
-            const bool vec_out = (a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-            f32x4 x0[PCH][PASSES];                       // the rows of the tile in flight (requested right after the previous tile was staged)
-            int c0n[PASSES];                             // their neighbour counts (0/0 rule)
-            int sidx[PASSES];                            // own-row indices of the NEXT tile to be requested
-            f32x4 prev[4];                               // epi 2: the earlier chunk's partial sums of the tile being finished
-            const bool has_index = a.self_index != nullptr;
-            const int32_t* index_or_any = has_index ? a.self_index : reinterpret_cast<const int32_t*>(a.x);   // [nn] ints are readable at either
-            const int32_t* cnt_or_any = nan_rule ? a.cnt : reinterpret_cast<const int32_t*>(a.x);
-            auto request_index = [&](int j) {
-                if constexpr (use_self) {
-                    const int tile = (int)blockIdx.x + min(j, nt - 1) * stride;          // past the block's last tile: a harmless repeat
-#pragma unroll
-                    for (int p = 0; p < PASSES; ++p) {
-                        const int g = min(tile * M + pw * RPW + p * RPP + sg, nn - 1);
-                        const int v = index_or_any[g];
-                        sidx[p] = has_index ? v : g;
-                    }
-                }
-            };
-            // global -> VGPRs, no wait, no lane-dependent branch near the loads (rows past the end and columns past the row width
-            // come from clamped addresses and are masked when the tile is staged)
-            auto request = [&](f32x4 (&xr)[PCH][PASSES], int (&xc)[PASSES], int j) {
-                const int tile = (int)blockIdx.x + j * stride;
-#pragma unroll
-                for (int pc = 0; pc < PCH; ++pc) {
-                    const bool is_agg = PCH == 2 ? pc == 1 : SRC == 0;                    // compile-time after unrolling
-#pragma unroll
-                    for (int p = 0; p < PASSES; ++p) {
-                        const int g = min(tile * M + pw * RPW + p * RPP + sg, nn - 1);
-                        if (is_agg) {
-                            xr[pc][p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + (int64_t)g * a.ldx + coff));
-                            xc[p] = cnt_or_any[g];
-                        } else {
-                            xr[pc][p] = *reinterpret_cast<const f32x4*>(a.self_tab + (int64_t)min(max(sidx[p], 0), a.self_rows - 1) * a.ld_self + coff);
-                        }
-                    }
-                }
-            };
-            // VGPRs -> mask -> split -> three bf16 LDS planes; returns the wave's rows that hold a huge value (bit = row - 8 pw)
-            auto stage = [&](f32x4 (&xr)[PCH][PASSES], int (&xc)[PASSES], int j) -> unsigned {
-                const int tile = (int)blockIdx.x + j * stride;
-                __bf16* buf = planes + (j & 1) * 3 * PL;
-                unsigned rows_bad = 0;
-#pragma unroll
-                for (int pc = 0; pc < PCH; ++pc) {
-                    const bool is_agg = PCH == 2 ? pc == 1 : SRC == 0;
-#pragma unroll
-                    for (int p = 0; p < PASSES; ++p) {
-                        const bool valid = col_ok && tile * M + pw * RPW + p * RPP + sg < nn;
-                        const bool nanrow = nan_rule && is_agg && xc[p] == 0;          // aggregators.py:60-61
-                        const float q = __builtin_nanf("");
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = valid ? (nanrow ? q : xr[pc][p][e]) : 0.f;
-                        const unsigned long long hb = __ballot(huge4(v));
-#pragma unroll
-                        for (int s = 0; s < RPP; ++s) {
-                            const unsigned long long grp = LG == 64 ? ~0ull : (((1ull << (LG & 63)) - 1ull) << (s * (LG & 63)));
-                            if (hb & grp) rows_bad |= 1u << (p * RPP + s);
-                        }
-                        bf16x4 hi, mid, lo;
-#ifdef PC_NO_SPLIT
-                        hi = __builtin_convertvector(v, bf16x4); mid = hi; lo = hi;
-#else
-                        split3(v, hi, mid, lo);
-#endif
-                        __bf16* dst = buf + (pw * RPW + p * RPP + sg) * LDB + pc * KP + c0;
-                        *reinterpret_cast<bf16x4*>(dst) = hi;
-                        *reinterpret_cast<bf16x4*>(dst + PL) = mid;
-                        *reinterpret_cast<bf16x4*>(dst + 2 * PL) = lo;
-                    }
-                }
-                if (rows_bad != 0 && lane == 0) {                         // the tile goes on the exact-redo list (duplicates are harmless)
-                    const int i = atomicAdd(&flags[1], 1);
-                    if (i < kListCap) flags[2 + i] = tile;
-                }
-                return rows_bad;
-            };
-            auto request_prev = [&](int j) {                             // epi 2: the partial sums the earlier chunk's launch left in `out`
-                if constexpr (EPI == 2) {
-                    const int tile = (int)blockIdx.x + j * stride;
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int g = min(tile * M + pw * RPW + 2 * it + (lane >> 5), nn - 1);
-                        const int col = min((lane & 31) * 4, max(a.out_dim - 4, 0));
-                        prev[it] = *reinterpret_cast<const f32x4*>(a.out + (int64_t)g * a.ldo + col);
-                    }
-                }
-            };
-            auto finish = [&](int j, unsigned rows_bad) {                // tile j: result plane -> (+ prev) -> activation -> out
-                const int tile = (int)blockIdx.x + j * stride;
-                float* pl = part + (size_t)(j & 1) * M * PLD;
-                const bool whuge = flags[0] != 0;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rl = 2 * it + (lane >> 5), row = pw * RPW + rl;
-                    const int col = (lane & 31) * 4;
-                    const int g = tile * M + row;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(pl + row * PLD + col);
-                    if (g < nn && col < a.out_dim) {
-                        if constexpr (EPI == 2) v += prev[it];
-                        if constexpr (EPI != 1) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = sage_activate(v[e], a.act);
-                        }
-                        if (whuge || ((rows_bad >> rl) & 1u)) continue;      // redone exactly below; other rows keep the MFMA result
-                        float* dst = a.out + (int64_t)g * a.ldo + col;
-                        if (col + 3 < a.out_dim && vec_out) {
-                            sage_store_stream<SAGE_H1_STORE>(reinterpret_cast<f32x4*>(dst), v);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (col + e < a.out_dim) __builtin_nontemporal_store(v[e], dst + e);
-                        }
-                    }
-                }
-            };
-
-            // phase 0: tile 0's rows are requested, the sum planes zeroed, tile 0 staged, tile 1 requested
-            unsigned bad0 = 0, bad1 = 0, bad2 = 0;                       // rows_bad of the tiles staged in this / the previous two phases
-            request_index(0);
-            request(x0, c0n, 0);
-            request_index(1);
-            bad0 = stage(x0, c0n, 0);
-            STAMP_T(256, 21);
-            if (nt > 1) { request(x0, c0n, 1); request_index(2); }
-            lds_barrier();
-            STAMP_T(256, 22);
-            // phases 1 .. nt: stage tile p (requested one phase ago: its rows travelled while this wave finished tile p - 3 and waited
-            // for the consumers), request tile p + 1, finish tile p - 2
-            for (int p = 1; p <= nt; ++p) {
-                bad2 = bad1; bad1 = bad0; bad0 = 0;
-#ifdef SAGE_DENSE_STAMPS
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                STAMP_T(256, 22 + 4 * (p - 1) + 1);        // loads of tile p have landed
-#endif
-                if (p < nt) bad0 = stage(x0, c0n, p);
-                STAMP_T(256, 22 + 4 * (p - 1) + 2);
-                if (p + 1 < nt) { request(x0, c0n, p + 1); request_index(p + 2); }
-                if (p >= 2) { request_prev(p - 2); finish(p - 2, bad2); }
-                STAMP_T(256, 22 + 4 * (p - 1) + 3);
-                lds_barrier();
-                STAMP_T(256, 22 + 4 * (p - 1) + 4);
-            }
-            // phase nt + 1: the last tile (staged in phase nt - 1: its rows_bad is bad1 now -- phase nt staged nothing)
-            request_prev(nt - 1);
-            finish(nt - 1, bad1);
-            STAMP_T(256, 38);
-        }
-        // Tiles that held |x| >= 2^127 / Inf / NaN (or all tiles, when W does): the exact fp32 fma chain.  Block-uniform; zero
-        // iterations on ordinary data.
-        __syncthreads();
-        STAMP_T(0, 39);
-        const int nbad = flags[1];
-        if (nbad > 0 || flags[0] != 0) {
-            const bool all = nbad > kListCap || flags[0] != 0;
-            const int per = M * a.out_dim;
-            for (int tb = (int)blockIdx.x, li = 0; all ? (tb < ntiles) : (li < nbad); tb += stride, ++li) {
-                const int tile = all ? tb : flags[2 + li];
-                for (int idx = tid; idx < per; idx += (int)blockDim.x) {
-                    const int g = tile * M + idx / a.out_dim, col = idx % a.out_dim;
-                    if (g < nn && (flags[0] != 0 || pc_row_is_huge(a, use_self, use_agg, g, nan_rule))) {
-                        const float v = pc_exact_dot(a, md, use_self, use_agg, g, col, nan_rule);
-                        a.out[(int64_t)g * a.ldo + col] = EPI == 1 ? v : sage_activate(v, a.act);
-                    }
-                }
-            }
-        }
-    }
-    sage_finish_block(a.fin, (int)gridDim.x);
-}
-
-template <int KP, int PCH, int SRC = 0, int EPI = 0>
-int launch_pc(const DenseArgs& a, const PcMode& md, hipStream_t st) {
-    constexpr int KPASS = PCH * KP;
-    constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 8) * sizeof(float) + 256;
-    static bool configured = false;
-    if (!configured) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_pc_kernel<KP, PCH, SRC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
-            return SAGE_ELAUNCH;
-        }
-        configured = true;
-    }
-    const int grid = min(sage_cdiv(a.n, 32), sage_tunables().dense_blocks);
-    hipLaunchKernelGGL((dense_pc_kernel<KP, PCH, SRC, EPI>), dim3(grid), dim3(512), lds, st, a, md);
-    SAGE_CHECK_LAUNCH("dense_pc_kernel");
     return SAGE_OK;
 }
 
@@ -1129,20 +708,11 @@ bool sage_layer_dense_supported(int32_t dim, int32_t out_dim) {
     return dim >= 4 && dim % 4 == 0 && out_dim >= 1 && out_dim <= 128;
 }
 
-// The 512-deep concat layer as two launches of the producer / consumer kernel (self chunk, then the means' chunk): possible when
-// the prepared planes exist and the output rows can be re-read 16 bytes at a time.
-bool sage_layer_dense_two_launches(int32_t dim, int32_t out_dim, int32_t concat, const void* weight_prepared, const float* out, int64_t ldo) {
-    return (sage_dense_pc_enabled() != 0 || sage_dense_two_enabled() != 0) && concat && weight_prepared && dim > 128 && dim <= 256 &&
-           sage_layer_dense_supported(dim, out_dim) && ldo % 4 == 0 && sage_aligned(out, 16) && out_dim % 4 == 0;
-}
-
-// parts: SAGE_DENSE_PART_SELF (the self chunk's partial sums -> out), SAGE_DENSE_PART_AGG (out = act(out + means' chunk)), or both
-// (= the whole layer; the only value accepted when sage_layer_dense_two_launches() is false)
 int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n, const int32_t* n_dev, int32_t concat,
                             const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
                             const int32_t* cnt, const int32_t* any_nonempty,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
-                            sage_finish_t fin, const void* weight_prepared, hipStream_t st, int parts) {
+                            sage_finish_t fin, const void* weight_prepared, hipStream_t st) {
     if (!sage_layer_dense_supported(dim, out_dim) || ldx % 4 != 0 || ldw % 4 != 0 || !sage_aligned(x, 16) ||
         !sage_aligned(weight, 16) || (concat && (ld_self % 4 != 0 || !sage_aligned(self_tab, 16)))) {
         sage_set_error("layer_dense: unsupported shape dim=%d out_dim=%d", dim, out_dim);
@@ -1153,54 +723,8 @@ int sage_launch_layer_dense(const float* x, int64_t ldx, int32_t dim, int32_t n,
                       self_index, cnt, any_nonempty, weight, ldw, out_dim, act, out, ldo, fin,
                       (const uint4*)weight_prepared};
     const int kp = dim <= 64 ? 64 : dim <= 128 ? 128 : 256;
-    const bool two = sage_layer_dense_two_launches(dim, out_dim, concat, weight_prepared, out, ldo);
-    if (parts != SAGE_DENSE_PART_ALL && !two) {
-        sage_set_error("layer_dense: this shape is one launch (parts = %d)", parts);
-        return SAGE_EINVAL;
-    }
     if (dim > 256) return concat ? launch_bf16x3<256, true, true>(a, st) : launch_bf16x3<256, false, true>(a, st);
 #ifndef SAGE_DENSE_FP32
-    if (weight_prepared && sage_dense_pc_enabled() != 0) {
-        // producer / consumer waves (dense_pc_kernel).  mode: {src, epi, wpass, wpasses, agg_woff}
-        if (!concat) {
-            const PcMode md{0, 0, 0, 1, 0};
-            return kp == 64 ? launch_pc<64, 1>(a, md, st) : kp == 128 ? launch_pc<128, 1>(a, md, st) : launch_pc<256, 1>(a, md, st);
-        }
-        if (kp < 256) {
-            const PcMode md{0, 0, 0, 1, dim};
-            return kp == 64 ? launch_pc<64, 2>(a, md, st) : launch_pc<128, 2>(a, md, st);
-        }
-        if (two) {
-            if (parts & SAGE_DENSE_PART_SELF) {
-                DenseArgs as = a;
-                as.fin = sage_finish_t{nullptr, nullptr};
-                if (!(parts & SAGE_DENSE_PART_AGG)) as.fin = fin;
-                const PcMode md{1, 1, 0, 2, dim};
-                if (int rc = launch_pc<256, 1, 1, 1>(as, md, st)) return rc;
-            }
-            if (parts & SAGE_DENSE_PART_AGG) {
-                const PcMode md{0, 2, 1, 2, dim};
-                if (int rc = launch_pc<256, 1, 0, 2>(a, md, st)) return rc;
-            }
-            return SAGE_OK;
-        }
-    }
-    if (two) {
-        // the lock-step kernel, one K chunk per launch (round 4): the nodes' own rows -> partial sums in `out`, then out = act(out + means' chunk)
-        if (parts & SAGE_DENSE_PART_SELF) {
-            DenseArgs as = a;
-            as.fin = (parts & SAGE_DENSE_PART_AGG) ? sage_finish_t{nullptr, nullptr} : fin;
-            as.cnt = nullptr;                          // the 0/0 rule belongs to the means' chunk
-            as.wpass = 0; as.wpasses = 2; as.woff = 0;
-            if (int rc = launch_bf16x3<256, false, false, true, 1, 1>(as, st)) return rc;
-        }
-        if (parts & SAGE_DENSE_PART_AGG) {
-            DenseArgs ag = a;
-            ag.wpass = 1; ag.wpasses = 2; ag.woff = dim;
-            if (int rc = launch_bf16x3<256, false, false, true, 0, 2>(ag, st)) return rc;
-        }
-        return SAGE_OK;
-    }
     if (!concat) {
         if (kp == 64) return launch_bf16x3<64, false>(a, st);
         if (kp == 128) return launch_bf16x3<128, false>(a, st);

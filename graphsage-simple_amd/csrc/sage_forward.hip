@@ -207,24 +207,14 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     }
     if (!ext_g) SAGE_EV(5);
     }
-    // ... and its contraction (one launch with the gather unless the layer is split); then layer 2.  The 512-deep concat layer is two
-    // launches (sage_dense.hip): the nodes' own rows' chunk -- which needs the sampling only, so the role pipeline asks for it alone
-    // (SAGE_STAGE_CONTRACT1_SELF) and runs it beside the gather -- then the means' chunk on top of its partial sums.
-    const bool two_launch = split1 && sage_layer_dense_two_launches(m->d0, m->h1, m->concat, m->w1_prepared, h1, m->h1);
-    if ((stages & SAGE_STAGE_CONTRACT1_SELF) && !(stages & SAGE_STAGE_CONTRACT1) && two_launch) {
-        if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
-                                             s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, m->w1_prepared, st,
-                                             SAGE_DENSE_PART_SELF))
-            return rc;
-    }
+    // ... and its contraction (one launch with the gather unless the layer is split); then layer 2
     if (stages & SAGE_STAGE_CONTRACT1) {
     SAGE_EV(6);
     if (gather_only1) {
         // nothing: the gather wrote h1
     } else if (split1) {
-        const int parts = (two_launch && !(stages & SAGE_STAGE_CONTRACT1_SELF)) ? SAGE_DENSE_PART_AGG : SAGE_DENSE_PART_ALL;
         if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
-                                             s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, m->w1_prepared, st, parts))
+                                             s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, m->w1_prepared, st))
             return rc;
     } else if (fuse1) {
         if (int rc = sage_launch_layer_fused(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
@@ -273,17 +263,6 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
 extern "C" int sage_forward2(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                              uint64_t seed, float* out, int64_t ldo, sage_stream_t stream) {
     return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, stream, nullptr);
-}
-
-bool sage_forward2_has_self_stage(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t batch) {
-    sage_ws_layout_t L;
-    if (!m || !workspace || sage_forward2_layout(m, m->ws_batch ? m->ws_batch : batch, &L) != SAGE_OK || L.total_bytes > workspace_bytes) return false;
-    char* ws = (char*)workspace;
-    float* agg1 = (float*)(ws + L.agg1);
-    float* h1 = (float*)(ws + L.h1);
-    const bool split1 = m->fused && L.layer1_split && sage_aligned(m->table, 16) && sage_aligned(m->w1, 16) &&
-                        sage_gather_is_sliced(m->d0, m->table_ld, m->d0, m->table, agg1, L.max_s1, m->k1);
-    return split1 && sage_layer_dense_two_launches(m->d0, m->h1, m->concat, m->w1_prepared, h1, m->h1);
 }
 
 // A subset of the forward's launches with the seeds and the sampler key taken from the call (sage_pipe.hip: one call per role stream)

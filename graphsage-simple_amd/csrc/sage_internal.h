@@ -59,11 +59,7 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
                             const float* self_tab, int64_t ld_self, int64_t self_rows, const int32_t* self_index,
                             const int32_t* cnt, const int32_t* any_nonempty,
                             const float* weight, int64_t ldw, int32_t out_dim, int32_t act, float* out, int64_t ldo, int32_t n_off,
-                            sage_finish_t fin, const void* weight_prepared, hipStream_t st, int parts = 3);
-#define SAGE_DENSE_PART_SELF 1
-#define SAGE_DENSE_PART_AGG  2
-#define SAGE_DENSE_PART_ALL  3
-bool sage_layer_dense_two_launches(int32_t dim, int32_t out_dim, int32_t concat, const void* weight_prepared, const float* out, int64_t ldo);
+                            sage_finish_t fin, const void* weight_prepared, hipStream_t st);
 
 // Measurement hook (sage_gather.hip): set by the thread that is about to launch the layer-1 gather, cleared right after.
 struct sage_ext_launch_t { void* start; void* stop; };
@@ -75,11 +71,7 @@ extern thread_local const sage_ext_launch_t* sage_ext_launch;
 #define SAGE_STAGE_GATHER1      4
 #define SAGE_STAGE_CONTRACT1    8     /* whole layer 1 when it is a one-launch layer */
 #define SAGE_STAGE_LAYER2       16
-#define SAGE_STAGE_CONTRACT1_SELF 32  /* concat layer 1 contracted in two launches (sage_layer_dense_two_launches): the nodes' own rows' chunk, which needs the
-                                         sampling only -- the role pipeline runs it beside the gather; together with SAGE_STAGE_CONTRACT1: both launches there */
-#define SAGE_STAGE_ALL          63
-// does SAGE_STAGE_CONTRACT1_SELF launch anything for this model / workspace?
-bool sage_forward2_has_self_stage(const sage_model_t* m, void* workspace, size_t workspace_bytes, int32_t batch);
+#define SAGE_STAGE_ALL          31
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                                 uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream);
 
@@ -100,20 +92,11 @@ struct sage_tunables_t {
     int sample_fused;             // SAGE_SAMPLE_FUSED    1: both hops in one launch when layer 2 is a one-launch layer; 0 (default): two launches
                                   //                      (measured: 24.3 us fused vs 10.3 + 11.4: the inner hop of a block's own winners is
                                   //                      three dependent rounds on 128-256 blocks instead of one round on 1500; pipeline 66.8 vs 66.2 us)
-    int dense_pc;                 // SAGE_DENSE_PC        1: contraction with producer / consumer waves (dense_pc_kernel) when the weight planes are prepared
-                                  //                      and rows are <= 256 wide; 0 (default): dense_bf16x3_kernel (all waves in lock step).  The producer /
-                                  //                      consumer kernel is faster alone (16.5 vs 17.7 us at config 3) and slower in the role pipeline (61.3 vs
-                                  //                      59.7 us per forward; concat 116 vs 91): its block holds 2 x 248 of a SIMD's 512 VGPRs, so nothing
-                                  //                      else fits on its CU, where the lock-step kernel's 2 x 168 leave room for the gather's waves
     int tile16_waves;             // SAGE_T16_WAVES       layer-2 tile16 kernel: 16 (1024-thread blocks) or 8 (512-thread blocks, default: 1.5 us per forward in the pipeline)
-    int dense_two;                // SAGE_DENSE_TWO       1: the 512-deep concat contraction as TWO launches of the lock-step kernel (the nodes' own rows' chunk, which
-                                  //                      the role pipeline runs beside the gather, then the means' chunk); 0: one two-pass launch
 };
 // n_words 32-bit words := v, as a kernel (hipMemsetAsync misbehaves inside replayed hipGraphs on ROCm 7.2: sage_api.hip)
 int sage_fill_u32(void* p, uint32_t v, size_t n_words, hipStream_t st);
 const sage_tunables_t& sage_tunables();
-int sage_dense_pc_enabled();          // SAGE_DENSE_PC, or what sage_set_option("dense_pc", ...) last said
-int sage_dense_two_enabled();         // SAGE_DENSE_TWO, or what sage_set_option("dense_two", ...) last said
 
 // Narrowest layer that takes the split form (column-sliced gather + dense contraction) instead of the one-launch layer.
 #ifndef SAGE_SPLIT_MIN_DIM

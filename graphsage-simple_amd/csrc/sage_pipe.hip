@@ -256,7 +256,7 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
                                                  SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
             return rc;
 #endif
-        return record(p, RS, slot, p->st[RG] != p->st[RS] || p->st[RD] != p->st[RS]);   // G waits for it, and D may (self chunk of a two-launch contraction)
+        return record(p, RS, slot, p->st[RG] != p->st[RS]);
     case RG:
         // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
         if (int rc = wait_on(p, RG, RS, slot, cap != 0)) return rc;
@@ -272,14 +272,7 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
 #endif
         return record(p, RG, slot, p->st[RD] != p->st[RG]);
     case RD:
-        // D: the contraction (or the whole fused layer 1).  The 512-deep concat layer is two launches: the nodes' own rows' chunk needs
-        // the sampling only and runs BESIDE the gather; the means' chunk adds itself to those partial sums once the gather is done
-#ifndef SAGE_PIPE_SKIP_D
-        if (sage_forward2_has_self_stage(m, ws, p->ws_bytes, p->batch)) {
-            if (int rc = wait_on(p, RD, RS, slot, cap != 0)) return rc;
-            if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1_SELF, p->st[RD])) return rc;
-        }
-#endif
+        // D: the contraction (or the whole fused layer 1)
         if (int rc = wait_on(p, RD, RG, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_D
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;

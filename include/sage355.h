@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 4
+#define SAGE_ABI_VERSION 5
 
 #define SAGE_OK            0
 #define SAGE_EINVAL       -1   /* bad argument (NULL, size, alignment, range) */
@@ -431,10 +431,8 @@ int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window);
 /* Every posted batch has been enqueued on the role streams (not: has run).  Returns the first error a role thread met. */
 int sage_pipe_flush(sage_pipe_t* p);
 
-/* Run-time options (ABI 4).  "dense_pc": 1 = contract rows of <= 256 floats with the producer / consumer kernel (csrc/sage_dense.hip,
- * dense_pc_kernel; needs prepared weight planes), 0 = with the lock-step kernel, -1 = the SAGE_DENSE_PC environment default (0).
- * Not thread safe against concurrent launches.  Replaces nothing in the reference. */
-int sage_set_option(const char* name, int32_t value);
+/* (ABI 5: sage_set_option is gone with the only option it carried -- the producer / consumer contraction kernel of round 3 was measured
+ * slower inside the pipeline and deleted in round 4.) */
 
 #ifdef __cplusplus
 }
