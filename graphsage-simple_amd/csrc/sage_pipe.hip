@@ -38,18 +38,6 @@
 // chain guarantees that an event is re-recorded (batch b + depth) only after its consumer's wait for batch b has been made.
 // Everything that looks at the streams from outside (join, fork, reset, update_weights, destroy) first drains the posted batches
 // (sage_pipe_flush).  Needs four distinct role streams; not available inside a stream capture.
-//
-// Flag hand-offs (round 4, sage_pipe_set_flags).  A kernel trace of the running pipeline (experiments/r04/dep_trace.py) shows what the
-// period is made of: on every role stream a kernel starts ~11 us after the LAST of its constraints was met (the gather: 21 us after the
-// previous gather had finished, with its samplers long done), while two kernels with nothing between them follow each other within a
-// microsecond.  The 11 us are the two barrier packets a hipEventRecord / hipStreamWaitEvent pair puts between the kernels of a stream;
-// stream G is busy kernel + bubble = period.  With a 256-byte block of device memory from the caller, the hand-offs are carried by
-// two one-thread kernels instead: `signal` (role r's stream, behind its kernel: flag[r] := batches completed, an agent-scope store) and
-// `gate` (the consumer's stream, in front of its kernel: spin, with s_sleep, until flag[r] has reached the batch's number).  The data
-// itself is published as before by the kernel boundaries (the producer's end-of-kernel release is complete before its signal kernel
-// starts; the consumer's kernel acquires when it starts, after the gate has ended); the flags are monotonic counters, so no host-side
-// order between the role threads is needed for them.  A gate gives up after two seconds (error word set) instead of hanging the queue.
-// Never inside a stream capture (the events stay there).
 #include <sched.h>
 #include <stdlib.h>
 
@@ -72,7 +60,6 @@ struct pipe_desc {                                      // one posted batch
     int slot;
     bool fresh;
     void* gev[2];
-    uint64_t seq;                                       // batches submitted before this one since the pipe was created (never reset): the flags' clock
 };
 }  // namespace
 
@@ -101,8 +88,6 @@ struct sage_pipe {
     char worker_err[512];
     pipe_desc ring[kRing];
     hipEvent_t ev_done[kDoneEvents];                    // window > 0: recorded on stream L behind batch b (index b % kDoneEvents)
-    unsigned long long* flags;                          // device, 256 B: [8 r] = batches role r has completed (monotonic), [28] = error word; NULL = events
-    uint64_t seq;                                       // batches ever submitted
     // while capturing: the graph node(s) layer 2 of the slot's last batch left as the tail of stream L, and the capture they belong to
     hipGraphNode_t cap_nodes[SAGE_PIPE_MAX_DEPTH][4];
     int cap_count[SAGE_PIPE_MAX_DEPTH];
@@ -131,40 +116,6 @@ static bool query_first() {
     static const bool on = [] { const char* v = getenv("SAGE_PIPE_QUERY"); return !(v && *v == '0'); }();
     return on;
 }
-// ---- flag hand-offs ------------------------------------------------------------------------------------------------------
-__global__ void pipe_signal_kernel(unsigned long long* flag, unsigned long long value) {
-    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one thread; polls past its L1 (agent-scope load) with s_sleep between the polls; bounded: ~2 s of the 100 MHz real-time counter
-__global__ void pipe_gate_kernel(const unsigned long long* flag, unsigned long long need, unsigned long long* err, unsigned long long max_ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(4);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) {
-            __hip_atomic_store(err, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
-}
-bool use_flags(const sage_pipe* p, unsigned long long cap) {
-    if (!p->flags || cap != 0) return false;
-    for (int r = 0; r < 4; ++r)
-        for (int q = 0; q < r; ++q)
-            if (p->st[q] == p->st[r]) return false;      // shared role streams keep the events (an event between two roles on one stream is skipped)
-    return true;
-}
-int flag_signal(sage_pipe* p, int role, uint64_t seq) {
-    hipLaunchKernelGGL(pipe_signal_kernel, dim3(1), dim3(1), 0, p->st[role], p->flags + 8 * role, (unsigned long long)(seq + 1));
-    SAGE_CHECK_LAUNCH("pipe_signal_kernel");
-    return SAGE_OK;
-}
-int flag_gate(sage_pipe* p, int consumer, int producer, uint64_t need) {
-    hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, p->st[consumer], p->flags + 8 * producer, (unsigned long long)need, p->flags + 28,
-                       200000000ull);                  // two seconds of the 100 MHz counter
-    SAGE_CHECK_LAUNCH("pipe_gate_kernel");
-    return SAGE_OK;
-}
-
 int wait_on(sage_pipe* p, int consumer, int producer, int slot, bool capturing = false) {
     if (p->st[consumer] == p->st[producer]) return SAGE_OK;          // stream order already says it
     if (!capturing && query_first() && hipEventQuery(p->ev[producer][slot]) == hipSuccess) return SAGE_OK;
@@ -231,8 +182,6 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     for (int r = 0; r < 4; ++r)
         for (int i = 0; i < depth; ++i) p->ev[r][i] = nullptr;
     p->ev_fork = nullptr;
-    p->flags = nullptr;
-    p->seq = 0;
     if (hipEventCreateWithFlags(&p->ev_fork, kEventFlags) != hipSuccess) {
         sage_set_error("pipe_create: hipEventCreate failed");
         delete p;
@@ -264,53 +213,6 @@ extern "C" int sage_pipe_destroy(sage_pipe_t* p) {
     return SAGE_OK;
 }
 
-// 256 bytes of zeroed, 256-byte aligned device memory the pipe may use for flag hand-offs for as long as it lives (NULL = back to events).
-// Call it on an idle pipe (before the first submit, or after join + synchronise).
-extern "C" int sage_pipe_set_flags(sage_pipe_t* p, void* flags_256B) {
-    SAGE_REQUIRE(p, "pipe_set_flags: NULL pipe");
-    SAGE_REQUIRE(!flags_256B || sage_aligned(flags_256B, 256), "pipe_set_flags: the block must be 256-byte aligned");
-    if (int rc = sage_pipe_flush(p)) return rc;
-    p->flags = nullptr;
-    if (!flags_256B) return SAGE_OK;
-    unsigned long long* f = (unsigned long long*)flags_256B;
-    for (int r = 0; r < 4; ++r)
-        for (int q = 0; q < r; ++q)
-            if (p->st[q] == p->st[r]) { sage_set_error("pipe_set_flags: flag hand-offs need four distinct role streams"); return SAGE_EUNSUPPORTED; }
-    // The flags continue the pipe's clock (batches submitted so far have all left the pipe: the caller says so) ...
-    for (int r = 0; r < 4; ++r) {
-        hipLaunchKernelGGL(pipe_signal_kernel, dim3(1), dim3(1), 0, p->st[r], f + 8 * r, (unsigned long long)p->seq);
-        SAGE_CHECK_LAUNCH("pipe_signal_kernel");
-    }
-    // ... and every hand-off edge is tried once: a gate on the consumer's stream (20 ms bound), THEN the signal on the producer's.  Two HIP
-    // streams that the runtime put on ONE hardware queue run in order: the signal would sit behind the spinning gate -- with events that
-    // costs time (82-93 us per forward instead of 59), with flags every hand-off would run into its time-out.  Such a pipe keeps the events.
-    const int edge[4][2] = {{RG, RS}, {RD, RG}, {RL, RD}, {RS, RL}};      // {consumer, producer}
-    for (int e = 0; e < 4; ++e) {
-        const int c = edge[e][0], pr = edge[e][1];
-        hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, p->st[c], f + 8 * pr, (unsigned long long)(p->seq + 1), f + 28, 2000000ull);
-        hipLaunchKernelGGL(pipe_signal_kernel, dim3(1), dim3(1), 0, p->st[pr], f + 8 * pr, (unsigned long long)(p->seq + 1));
-        SAGE_CHECK_LAUNCH("pipe hand-off self-test");
-        if (hipStreamSynchronize(p->st[c]) != hipSuccess || hipStreamSynchronize(p->st[pr]) != hipSuccess) {
-            sage_set_error("pipe_set_flags: hipStreamSynchronize failed");
-            return SAGE_ELAUNCH;
-        }
-        hipLaunchKernelGGL(pipe_signal_kernel, dim3(1), dim3(1), 0, p->st[pr], f + 8 * pr, (unsigned long long)p->seq);     // back to the clock
-        SAGE_CHECK_LAUNCH("pipe_signal_kernel");
-    }
-    unsigned long long err = 0;
-    for (int r = 0; r < 4; ++r)
-        if (hipStreamSynchronize(p->st[r]) != hipSuccess) { sage_set_error("pipe_set_flags: hipStreamSynchronize failed"); return SAGE_ELAUNCH; }
-    if (hipMemcpy(&err, f + 28, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) { sage_set_error("pipe_set_flags: hipMemcpy failed"); return SAGE_ELAUNCH; }
-    if (err != 0) {
-        err = 0;
-        (void)hipMemcpy(f + 28, &err, sizeof(err), hipMemcpyHostToDevice);
-        sage_set_error("pipe_set_flags: two role streams share a hardware queue (a gate kernel timed out in the self-test): the pipe keeps hipEvent hand-offs");
-        return SAGE_EUNSUPPORTED;
-    }
-    p->flags = f;
-    return SAGE_OK;
-}
-
 extern "C" int sage_pipe_update_weights(sage_pipe_t* p, const float* w1, const float* w2, const void* w1_prepared) {
     SAGE_REQUIRE(p && w1 && w2, "pipe_update_weights: NULL argument");
     if (int rc = sage_pipe_flush(p)) return rc;          // the role threads read p->model
@@ -328,7 +230,6 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
     const sage_model_t* m = &p->model;
     const int slot = d.slot;
     void* ws = p->ws[slot];
-    const bool fl = use_flags(p, cap);
     switch (r) {
     case RS:
         // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
@@ -345,9 +246,7 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
             } else {
                 SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset "
                                                    "(after synchronising) before submitting eagerly again");
-                if (fl) {
-                    if (int rc = flag_gate(p, RS, RL, d.seq + 1 - (uint64_t)p->depth)) return rc;      // the slot's previous batch has left layer 2
-                } else if (int rc = wait_on(p, RS, RL, slot, cap != 0)) return rc;
+                if (int rc = wait_on(p, RS, RL, slot, cap != 0)) return rc;
             }
         }
 #ifndef SAGE_PIPE_SKIP_S   // diagnostic builds only (experiments/ab_build.sh).  _G and _D may be skipped alone (stale data downstream); _S and _L
@@ -357,13 +256,10 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
                                                  SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
             return rc;
 #endif
-        if (fl) return flag_signal(p, RS, d.seq);
         return record(p, RS, slot, p->st[RG] != p->st[RS]);
     case RG:
         // G: the layer-1 gather (nothing to launch when layer 1 is a one-launch layer; D then waits on S through G's stream order)
-        if (fl) {
-            if (int rc = flag_gate(p, RG, RS, d.seq + 1)) return rc;
-        } else if (int rc = wait_on(p, RG, RS, slot, cap != 0)) return rc;
+        if (int rc = wait_on(p, RG, RS, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_G   // diagnostic builds (experiments/ab_build.sh): the pipeline without one of its stages' kernels, stale data downstream
         {
             // profiled submit: the two caller-owned timing events become the gather launch's OWN start / stop events (sage_gather.hip)
@@ -374,27 +270,20 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
             if (rc) return rc;
         }
 #endif
-        if (fl) return flag_signal(p, RG, d.seq);
         return record(p, RG, slot, p->st[RD] != p->st[RG]);
     case RD:
         // D: the contraction (or the whole fused layer 1)
-        if (fl) {
-            if (int rc = flag_gate(p, RD, RG, d.seq + 1)) return rc;
-        } else if (int rc = wait_on(p, RD, RG, slot, cap != 0)) return rc;
+        if (int rc = wait_on(p, RD, RG, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_D
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
 #endif
-        if (fl) return flag_signal(p, RD, d.seq);
         return record(p, RD, slot, p->st[RL] != p->st[RD]);
     default:
         // L: layer 2; afterwards the workspace is clean again
-        if (fl) {
-            if (int rc = flag_gate(p, RL, RD, d.seq + 1)) return rc;
-        } else if (int rc = wait_on(p, RL, RD, slot, cap != 0)) return rc;
+        if (int rc = wait_on(p, RL, RD, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_L
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
 #endif
-        if (fl) return flag_signal(p, RL, d.seq);
         return record(p, RL, slot, p->st[RS] != p->st[RL]);
     }
 }
@@ -555,7 +444,6 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     d.fresh = fresh_slot;
     d.gev[0] = gather_events ? gather_events[0] : nullptr;
     d.gev[1] = gather_events ? gather_events[1] : nullptr;
-    d.seq = p->seq++;
     const int slot = d.slot;
     if (p->threaded) {
         SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset first");

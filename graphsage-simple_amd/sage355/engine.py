@@ -512,7 +512,7 @@ class RolePipeline:
     The reference has no counterpart (model.py:240-252 is one batch at a time on the host)."""
 
     def __init__(self, rowptr, col, table, w1, w2, k1, k2, batch, depth=4, roles="SGDL", priorities=None, streams=None, threads=None,
-                 window=None, flags=None, **engine_kwargs):
+                 window=None, **engine_kwargs):
         import ctypes
         import os
         if depth < 1 or depth > native.PIPE_MAX_DEPTH:
@@ -544,21 +544,6 @@ class RolePipeline:
                      "pipe_create")
         self._wkey = self._weights_key()
         self._keep = []
-        # flag hand-offs (sage_pipe_set_flags): one-thread signal / gate kernels on device counters instead of hipEvent record / wait pairs
-        # between the kernels of a role stream.  Default on with four distinct role streams; flags=False / SAGE_PIPE_FLAGS=0 keeps the events
-        if flags is None:
-            flags = os.environ.get("SAGE_PIPE_FLAGS", "1") != "0"
-        self.flags = None
-        if flags and len(names) == 4:
-            self.flags = torch.zeros(64, dtype=torch.int64, device=self.device)      # 512 B; the library uses the first 256-byte aligned 256 B
-            torch.cuda.current_stream().synchronize()
-            off = (-self.flags.data_ptr()) % 256 // 8
-            self._flags_view = self.flags[off:off + 32]
-            rc = native.lib().sage_pipe_set_flags(self._h, self._flags_view.data_ptr())
-            if rc == native.EUNSUPPORTED:          # two role streams on one hardware queue (the library's self-test): the events stay
-                self.flags = None
-            else:
-                native.check(rc, "pipe_set_flags")
         # host enqueue threads (one per role stream; sage_pipe_set_threads): submit() then only posts the batch.  Opt-in (threads=True or
         # SAGE_PIPE_THREADS=1), because a caller that synchronises the device itself must then flush() first; bench.py opts in
         if threads is None:
@@ -576,10 +561,6 @@ class RolePipeline:
             self._window = int(window)
         native.check(native.lib().sage_pipe_set_threads(self._h, 1 if on else 0, self._window), "pipe_set_threads")
         self.threads = bool(on)
-
-    def gate_timeouts(self):
-        """0, or the batch number a gate kernel of the flag hand-offs gave up waiting for (after two seconds): a producer never signalled."""
-        return 0 if self.flags is None else int(self._flags_view[28].item())
 
     def flush(self):
         """Every submitted batch has been ENQUEUED on the role streams (host enqueue threads; a no-op without them).  Call it

@@ -30,7 +30,7 @@ SYMBOLS = [
     "sage_two_hop_grad_w1_workspace_bytes", "sage_two_hop_grad_w1",
     "sage_prepared_weight_bytes", "sage_prepare_weights",
     "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_profiled", "sage_pipe_submit_many",
-    "sage_pipe_join", "sage_pipe_fork", "sage_pipe_reset", "sage_pipe_set_threads", "sage_pipe_flush", "sage_pipe_set_flags",
+    "sage_pipe_join", "sage_pipe_fork", "sage_pipe_reset", "sage_pipe_set_threads", "sage_pipe_flush",
 ]
 PIPE_MAX_DEPTH = 8
 
@@ -139,7 +139,6 @@ def lib():
     L.sage_pipe_reset.argtypes = [P]
     L.sage_pipe_set_threads.argtypes = [P, I32, I32]
     L.sage_pipe_flush.argtypes = [P]
-    L.sage_pipe_set_flags.argtypes = [P, P]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name == "sage_prepared_weight_bytes" or name.endswith("_workspace_bytes"):

@@ -430,14 +430,6 @@ int sage_pipe_reset(sage_pipe_t* p);
 int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window);
 /* Every posted batch has been enqueued on the role streams (not: has run).  Returns the first error a role thread met. */
 int sage_pipe_flush(sage_pipe_t* p);
-/* Flag hand-offs (ABI 5).  flags_256B: 256 bytes of ZEROED, 256-byte aligned device memory that stays valid while the pipe lives.  With it
- * (and four distinct role streams, outside stream capture) the stage hand-offs S -> G -> D -> L -> S(+depth) are carried by one-thread
- * `signal` / `gate` kernels on monotonic device counters instead of hipEventRecord / hipStreamWaitEvent pairs: the two barrier packets such
- * a pair puts between two kernels of a stream cost ~11 us per kernel on this part, a one-thread kernel about one (csrc/sage_pipe.hip).
- * A gate gives up after two seconds and writes the batch number it waited for to 64-bit word 28 of the block (0 = no time-out so far).
- * NULL returns to events.  Call on an idle pipe: the call synchronises the role streams (it tries every hand-off edge once; two role streams
- * that the runtime put on one hardware queue cannot hand off by flags: SAGE_EUNSUPPORTED, the events stay).  Results are bit-identical either way. */
-int sage_pipe_set_flags(sage_pipe_t* p, void* flags_256B);
 
 /* (ABI 5: sage_set_option is gone with the only option it carried -- the producer / consumer contraction kernel of round 3 was measured
  * slower inside the pipeline and deleted in round 4.) */
