@@ -5,7 +5,7 @@ T=${2:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/matrix; mkdir -p $O
 cd $R
-run(){ name=$1; shift; timeout -k 10 500 python bench.py --steps $S --cpu-seconds 0 --no-variant "$@" > $O/$name.json 2> $O/$name.err || { echo "$name FAILED"; tail -3 $O/$name.err; return 0; }
+run(){ name=$1; shift; timeout -k 10 500 python bench.py --steps $S --cpu-seconds 0 --no-variant --scale-variant off "$@" > $O/$name.json 2> $O/$name.err || { echo "$name FAILED"; tail -3 $O/$name.err; return 0; }
   python3 -c "
 import json; d=json.load(open('$O/$name.json')); r=d['roofline']
 print('$name', 'us/fwd %.1f' % (1e3*d['ms_per_step']), 'emb/s %.3g' % d['value'], 'parity %.1e' % d['parity_max_err_vs_fp64_oracle'], 'fwd_frac', r['forward_frac'], 'frac', r['frac'], 'alone', r['frac_alone'], {k: round(v*1e3,1) for k,v in r['stage_ms_alone'].items()})"; }

@@ -7,10 +7,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${TAG}_mstats; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 run(){ name=$1; shift
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$name" -- python3 "$R/bench.py" --steps 100 --cpu-seconds 0 --no-variant "$@" \
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$name" -- python3 "$R/bench.py" --steps 100 --cpu-seconds 0 --no-variant --scale-variant off "$@" \
       > "$O/$name.json" 2> "$O/$name.log"; echo "$name rc=$?"
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${name}_alone" -- python3 "$R/bench.py" --steps 60 --warmup 10 --exec direct --streams 1 \
-      --no-parity --cpu-seconds 0 --no-variant "$@" > "$O/${name}_alone.json" 2> "$O/${name}_alone.log"; echo "${name}_alone rc=$?"
+      --no-parity --cpu-seconds 0 --no-variant --scale-variant off "$@" > "$O/${name}_alone.json" 2> "$O/${name}_alone.log"; echo "${name}_alone rc=$?"
 }
 run c3_concat --config 3 --mode concat
 run c4_rmat23 --config 4
