@@ -35,7 +35,6 @@ for p in (REPO, os.path.join(REPO, "graphsage-simple_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-_ROLE_STREAMS = {}          # roles map -> the role streams of the process's first pipeline (reused by every later one)
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 CACHE_DIR = os.environ.get("SAGE_CACHE", "/tmp/sage_cache")
 
@@ -400,13 +399,11 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
     engines, streams, outs = [], [], []
     pipe_graphs = None
     if exec_mode in ("pipe", "pipegraph"):
-        # every role pipeline of this process runs on the FIRST one's role streams: which hardware queue a NEW HIP stream lands on is the
-        # runtime's choice, and two role streams on one queue serialise (configs[3] as the second workload of a process: 97.8 us per
-        # forward on fresh streams against 83-84 when it is the process's first pipeline)
+        # (every RolePipeline of a process runs on its first pipeline's role streams -- sage355.engine: configs[3] as the second workload
+        #  read 97.8 us per forward on fresh streams that shared a hardware queue, 82.4 on the first pipeline's)
         pipe = RolePipeline(rowptr, col, table, w1, w2, k1, k2, batch=b, depth=args.depth, roles=args.roles,
-                            priorities={ch: -1 for ch in args.high_priority}, streams=_ROLE_STREAMS.get(args.roles),
+                            priorities={ch: -1 for ch in args.high_priority},
                             threads=host["role_threads"] and exec_mode == "pipe", window=args.window, **ekw)
-        _ROLE_STREAMS.setdefault(args.roles, pipe.distinct_streams())
         pipe_out = torch.empty(max(args.depth, 4), b, h2, device=dev)
         torch.cuda.synchronize()
         if exec_mode == "pipegraph":

@@ -501,6 +501,9 @@ class TwoHopEngine:
 
 
 
+_PROCESS_ROLE_STREAMS = {}          # (device, distinct role letters, priorities) -> the role streams of the process's first such pipeline
+
+
 class RolePipeline:
     """Consecutive 2-hop forwards software-pipelined over ROLE STREAMS (sage_pipe_*, include/sage355.h).
 
@@ -527,14 +530,20 @@ class RolePipeline:
             if ch not in names:
                 names.append(ch)
         priorities = priorities or {}
-        if streams is not None:
-            # reuse another pipe's role streams (e.g. a pipe that was just destroyed): which hardware queue a NEW HIP stream lands
-            # on is the runtime's choice, and two role streams on one queue serialise (82-93 us per forward instead of 66-74)
+        # Which hardware queue a NEW HIP stream lands on is the runtime's choice, and two role streams on one queue serialise (82-105 us per
+        # forward instead of 59-90, seen for the second pipeline of a process).  So every pipeline of a process runs on the role streams
+        # of the FIRST one with the same (device, role map, priorities) unless the caller hands in streams of its own or asks for new
+        # ones (streams="new"); pipes that share streams and are used at the same time interleave in stream order, which is still correct.
+        key = (str(self.device), "".join(names), tuple(int(priorities.get(ch, 0)) for ch in names))
+        if streams is None and key in _PROCESS_ROLE_STREAMS:
+            streams = _PROCESS_ROLE_STREAMS[key]
+        if streams is not None and not isinstance(streams, str):
             if len(streams) != len(names):
                 raise native.SageError(f"RolePipeline: {len(names)} distinct role streams needed, {len(streams)} given")
             self._streams = dict(zip(names, streams))
         else:
             self._streams = {ch: torch.cuda.Stream(device=self.device, priority=int(priorities.get(ch, 0))) for ch in names}
+            _PROCESS_ROLE_STREAMS.setdefault(key, list(self._streams.values()))
         self.role_streams = [self._streams[ch] for ch in roles]
         ws = (ctypes.c_void_p * depth)(*[e.workspace.data_ptr() for e in self.engines])
         st = (ctypes.c_void_p * 4)(*[s.cuda_stream for s in self.role_streams])
