@@ -586,16 +586,25 @@ class RolePipeline:
             raise native.SageError("RolePipeline: an earlier submit failed half-way; synchronise, drop this pipe and create a new one")
 
     def _weights_key(self):
-        w1, w2 = self.engines[0]._weights()
-        return (w1.data_ptr(), w2.data_ptr(), w1._version, w2._version)
+        e0 = self.engines[0]
+        w1, w2 = e0._weights()
+        return (w1.data_ptr(), w2.data_ptr(), w1._version, w2._version, e0.table._version)
 
     def _sync_weights(self):
+        """Weights or table written in place since the last submit (version counters): re-prepare the weight planes / refresh the
+        slice-major table copy on the CURRENT stream -- the stream such a write was made on -- and make the role streams wait for it."""
         key = self._weights_key()
         if key != self._wkey:
-            m = self.engines[0]._model()          # re-prepares the weight planes on the current stream
+            m = self.engines[0]._model()          # re-prepares the weight planes, refreshes the slice-major copy in place: current stream
             native.check(native.lib().sage_pipe_update_weights(self._h, m.w1, m.w2, m.w1_prepared), "pipe_update_weights")
             self.fork()                           # the role streams wait for that
             self._wkey = key
+
+    def refresh_table(self):
+        """The table was written without moving its version counter (`.data`, a collective): refresh the engine's slice-major copy in
+        place and order the role streams behind it (and behind whatever wrote the table on the current stream)."""
+        self.engines[0].refresh_table()
+        self.fork()
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -102,12 +102,11 @@ def test_slice_major_copy_is_refreshed_in_place_under_a_live_pipe():
     tdev.mul_(2.0)                                       # in place: the version counter moves
     fresh = TwoHopEngine(rowptr, col, tdev.clone(), w1.to(DEV), w2.to(DEV), k1, k2, max_batch=b)
     want = fresh.forward(seeds, seed=5)
-    e0._model()                                          # what the next engine-level call does: notices the version, refreshes in place
+    pipe.submit(seeds, 5, out[1]); pipe.synchronize()    # the submit notices the version: refresh in place, role streams forked behind it
     assert e0._table_sliced.data_ptr() == ptr
-    pipe.submit(seeds, 5, out[1]); pipe.synchronize()
     assert torch.equal(out[1], want) and not torch.equal(out[1], before)
     tdev.data.mul_(0.5)                                  # `.data`: no version bump -> explicit refresh
-    e0.refresh_table()
+    pipe.refresh_table()
     assert e0._table_sliced.data_ptr() == ptr
     pipe.submit(seeds, 5, out[1]); pipe.synchronize()
     assert torch.equal(out[1], before)
