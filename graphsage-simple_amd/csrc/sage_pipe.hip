@@ -116,28 +116,8 @@ static bool query_first() {
     static const bool on = [] { const char* v = getenv("SAGE_PIPE_QUERY"); return !(v && *v == '0'); }();
     return on;
 }
-// SAGE_PIPE_JIT = role letters (e.g. "G"): that role's HOST thread waits for its producer's event (hipEventQuery) and then launches with
-// no wait packet in the queue -- with the producer batches ahead in GPU time (stream S under a deep pipeline) the launch is still enqueued
-// while the stream's previous kernel runs, and the bubble between two kernels of the stream loses one of its two barrier packets.
-// Host enqueue threads only (the submitting thread must never block on the GPU).  Round 3 measured the all-roles form at depth 4: slower.
-static unsigned jit_roles() {
-    static const unsigned m = [] {
-        unsigned x = 0;
-        if (const char* v = getenv("SAGE_PIPE_JIT"))
-            for (; *v; ++v) x |= (*v == 'S') ? 1u : (*v == 'G') ? 2u : (*v == 'D') ? 4u : (*v == 'L') ? 8u : 0u;
-        return x;
-    }();
-    return m;
-}
 int wait_on(sage_pipe* p, int consumer, int producer, int slot, bool capturing = false) {
     if (p->st[consumer] == p->st[producer]) return SAGE_OK;          // stream order already says it
-    if (!capturing && p->threaded && (jit_roles() >> consumer & 1u)) {
-        for (unsigned n = 0; hipEventQuery(p->ev[producer][slot]) == hipErrorNotReady; ++n) {
-            if (p->stop.load(std::memory_order_relaxed)) break;
-            if (n > 64) __builtin_ia32_pause();
-        }
-        return SAGE_OK;
-    }
     if (!capturing && query_first() && hipEventQuery(p->ev[producer][slot]) == hipSuccess) return SAGE_OK;
     if (hipStreamWaitEvent(p->st[consumer], p->ev[producer][slot], 0) != hipSuccess) {
         sage_set_error("pipe: hipStreamWaitEvent failed");
