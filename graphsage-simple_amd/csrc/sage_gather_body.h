@@ -276,12 +276,7 @@ __device__ __forceinline__ void gather_sliced_block_rows(
                 if (SLOT) x = slot_rows[max(x, 0)];
                 extra = extra && !(j0 + u < c && x == s);           // aggregators.py:50-51: set union
                 x = min(max(x, 0), last_row);
-#ifdef SAGE_G_NT_POS           /* EXPERIMENT build: list positions >= SAGE_G_NT_POS are requested with streaming loads (hot-first lists) */
-                if (u >= (SAGE_G_NT_POS)) t[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(tcol + (int64_t)x * ld));
-                else t[u] = *reinterpret_cast<const V*>(tcol + (int64_t)x * ld);
-#else
                 t[u] = *reinterpret_cast<const V*>(tcol + (int64_t)x * ld);
-#endif
             }
 #pragma unroll
             for (int u = 0; u < TRIP; ++u) {

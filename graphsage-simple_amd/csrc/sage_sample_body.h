@@ -136,33 +136,11 @@ __device__ __forceinline__ void sample_block(
         if (wl.seeds && !active && gl == 0) wl.seeds[tid / G] = -1;
         const bool floyd = active && deg > (int64_t)k;
         const uint32_t pos = sage_group_positions<G>(floyd, deg, k, v, (r < tag_self_rows) ? tag_self : tag, key0, key1, gl, lane);
-#ifdef SAGE_S_HOTFIRST      /* EXPERIMENT build (experiments/r04/call16.sh): the inner hop writes a node's sampled ids HOT FIRST (id < SAGE_S_HOTFIRST in the
-                               engine's degree order), so that the gather can load late list positions -- mostly cold rows -- with streaming loads */
-        if (active && gl < c) id = __builtin_nontemporal_load(col + s + (int64_t)pos);
-        if constexpr (!FRONTIER) {
-            const bool has = active && gl < c;
-            const bool hot = has && id < (SAGE_S_HOTFIRST);
-            const unsigned long long bh = __ballot(hot), ba = __ballot(has);
-            const unsigned gm = (G == kWave) ? 0xFFFFFFFFu : ((1u << (G & 31)) - 1u);
-            const unsigned gh = (unsigned)(bh >> (lane - gl)) & gm, ga = (unsigned)(ba >> (lane - gl)) & gm;
-            const unsigned below = (1u << gl) - 1u;
-            const int npos = hot ? __popc(gh & below) : __popc(gh) + __popc((ga & ~gh) & below);
-            if (active) {
-                if (has) nbr[(int64_t)r * k + npos] = id;
-                else if (gl < k) nbr[(int64_t)r * k + gl] = -1;
-                if (gl == 0) cnt[r] = c;
-            }
-        } else if (active) {
-            if (gl < k) nbr[(int64_t)r * k + gl] = id;
-            if (gl == 0) cnt[r] = c;
-        }
-#else
         if (active) {
             if (gl < c) id = __builtin_nontemporal_load(col + s + (int64_t)pos);   // one 4-byte read per drawn position: streaming
             if (gl < k) nbr[(int64_t)r * k + gl] = id;
             if (gl == 0) cnt[r] = c;
         }
-#endif
     } else {
         if (active) {
             if (nodes && (insert_self || bs.nodes_copy)) {
