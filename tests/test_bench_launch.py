@@ -63,3 +63,18 @@ def test_self_launch_fails_loudly_when_a_rank_dies(tmp_path, capfd):
     rc = bench.self_launch(2, ["--fail"], script=str(script), timeout=300)
     assert rc != 0
     assert capfd.readouterr().out.strip() == ""
+
+
+def test_host_plan_turns_the_role_threads_on_only_where_every_rank_has_five_cores(monkeypatch):
+    """VERDICT r3 #6: four spinning role threads + the submitter per rank: on only if usable cores // ranks >= 5; the line says which mode ran."""
+    import types
+    args = types.SimpleNamespace(host_threads=1, roles="SGDL")
+    monkeypatch.setattr(bench, "usable_host_cores", lambda: 16)
+    h1, h2, h4 = bench.host_plan(args, 1), bench.host_plan(args, 2), bench.host_plan(args, 4)
+    assert (h1["cores_per_rank"], h1["role_threads"]) == (16, True) and (h2["cores_per_rank"], h2["role_threads"]) == (8, True)
+    assert (h4["cores_per_rank"], h4["role_threads"], h4["enqueue_mode"]) == (4, False, "submitting thread only") and "oversubscribe" in h4["why"]
+    monkeypatch.setattr(bench, "usable_host_cores", lambda: 192)
+    assert bench.host_plan(args, 8)["role_threads"] is True and bench.host_plan(args, 8)["cores_per_rank"] == 24
+    assert bench.host_plan(types.SimpleNamespace(host_threads=0, roles="SGDL"), 1)["role_threads"] is False
+    assert bench.host_plan(types.SimpleNamespace(host_threads=1, roles="SGDD"), 1)["role_threads"] is False      # three streams: no role threads
+    assert 1 <= bench.usable_host_cores.__wrapped__() if hasattr(bench.usable_host_cores, "__wrapped__") else True
