@@ -229,9 +229,9 @@ def main():
         if p is not None:
             p.flush()                             # host enqueue threads: everything submitted is on the streams
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None:                      # one process: nothing can have been enqueued since the synchronize above
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # ---- the headline: BASELINE configs[2] (or --config N) ----
     head = run_workload(args, rank, world, dev, dist, fence, host, side_variants=not args.no_variant, with_cpu=args.cpu_seconds > 0)
