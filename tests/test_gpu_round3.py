@@ -167,7 +167,8 @@ def _reference_loop(feat_data, labels, adj_lists, num_classes, seed, sample_seed
 
 def test_reference_loop_shape_with_the_drop_in_classes_trains_at_engine_speed():
     """The reference's training loop (model.py:240-252), its classes swapped for the drop-in ones by the import line alone,
-    cuda=False: <= 1.5 ms per 256-seed step in the median AND <= 2.5 ms in the mean (the reference: 140-180 ms per step on a CPU,
+    cuda=False: <= 1.5 ms per 256-seed step in the median AND <= 2.5 ms in the mean (measured since the cap: median 0.84-0.93 ms, mean
+    0.84-0.94 ms over five runs, experiments/r04/call23.sh; round 3: median 0.69, mean 3.15; the reference: 140-180 ms per step on a CPU,
     SURVEY 8c; this path before round 3: 10-12 ms, layer 2 sampled by Python sets).  The F1 of this very loop against the reference's
     distribution over sampling streams is tests/test_gpu_train.py::test_f1_distribution_over_sampling_streams_matches_the_reference
     (path "dropin").
@@ -187,8 +188,8 @@ def test_reference_loop_shape_with_the_drop_in_classes_trains_at_engine_speed():
     encoders._threads_capped = False               # as in a fresh process: the first cuda=False forward caps the pool
     try:
         torch.manual_seed(0)
-        f1, times, losses, enc2 = _reference_loop(feats, labels, adj, 7, 1, 1, 4, 256, False)
-        assert torch.get_num_threads() <= usable_cores()
+        f1, times, losses, enc2 = _reference_loop(feats, labels, adj, 7, 1, 1, 8, 256, False)      # 8 epochs: 72 steps, so that ONE host hiccup of tens
+        assert torch.get_num_threads() <= usable_cores()                                             # of milliseconds does not decide the mean
     finally:
         torch.set_num_threads(threads)
     assert enc2._engine is not None and enc2._engine.generation > 0
