@@ -595,6 +595,7 @@ class RolePipeline:
         slice-major table copy on the CURRENT stream -- the stream such a write was made on -- and make the role streams wait for it."""
         key = self._weights_key()
         if key != self._wkey:
+            self.join()                           # batches still in the pipe read the planes / the copy that are about to be rewritten
             m = self.engines[0]._model()          # re-prepares the weight planes, refreshes the slice-major copy in place: current stream
             native.check(native.lib().sage_pipe_update_weights(self._h, m.w1, m.w2, m.w1_prepared), "pipe_update_weights")
             self.fork()                           # the role streams wait for that
@@ -603,6 +604,7 @@ class RolePipeline:
     def refresh_table(self):
         """The table was written without moving its version counter (`.data`, a collective): refresh the engine's slice-major copy in
         place and order the role streams behind it (and behind whatever wrote the table on the current stream)."""
+        self.join()
         self.engines[0].refresh_table()
         self.fork()
 
