@@ -494,12 +494,14 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
     if pipe is not None:
         pipe.flush()
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # until the last HIP call of the region was made (it must stay below ms_per_step)
+    torch.cuda.synchronize()
+    own_done = time.perf_counter() - t0                                  # this rank's K steps have left the GPU (N > 1: reported, never `value`)
     fence(pipe)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed, own_done], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, own_done = float(t[0].item()), float(t[1].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * b * args.steps / elapsed
 
@@ -776,6 +778,12 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
                        "batch_per_gpu": b, "global_batch": b * world, "fanout": [k1, k2], "encoder_mode": args.mode,
                        "execution": execution, "host_enqueue_ms_per_step": round(host_enqueue_ms, 5),
                        "host_submit_ms_per_step": round(host_submit_ms, 5), "fused_layers": not args.unfused,
+                       # N > 1: what the closing barrier itself adds to the K-step region (`value` includes it, as the contract's bracket does)
+                       "closing_fence": None if dist is None else {
+                           "slowest_rank_done_ms_per_step": round(own_done / args.steps * 1e3, 5),
+                           "barrier_us_in_timed_region": round((elapsed - own_done) * 1e6, 1),
+                           "note": "ms_per_step / value are taken AFTER synchronize + dist.barrier + synchronize on every rank (max over ranks); "
+                                   "slowest_rank_done is the max over ranks of the time at which a rank's own K steps had completed"},
                        "preheat": f"{preheat_forwards} untimed forwards on throw-away batches before the {args.warmup} warm-up steps (GPU clock ramp)",
                        "node_order": args.node_order if args.config != 2 else "original",
                        "engine_layout": (relabel or "input") + (" (internal: rows by descending degree; seeds arrive in the generator's ids and are "

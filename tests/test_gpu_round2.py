@@ -300,6 +300,10 @@ def test_bench_two_ranks_say_how_the_pipeline_was_fed():
     assert h["role_threads"] == (h["cores_per_rank"] >= 5) and h["enqueue_mode"] in ("one host thread per role stream", "submitting thread only")
     assert ("host enqueue thread" in line["config"]["execution"]) == h["role_threads"]
     assert line["timed_path_check"]["bit_identical_to_oracle_gated_forward"] is True
+    # N > 1: the line says what the closing barrier added to the K-step region; `value` keeps the contract's bracket (after the barrier)
+    cf = line["config"]["closing_fence"]
+    assert 0 < cf["slowest_rank_done_ms_per_step"] <= line["ms_per_step"] + 1e-5 and cf["barrier_us_in_timed_region"] >= 0
+    assert abs(line["value"] - 2 * 4096 / (line["ms_per_step"] * 1e-3)) <= 2e-3 * line["value"]
 
 
 # ------------------------------------------------------------------------------------------ the split-bf16 contraction, adversarially
