@@ -38,6 +38,14 @@
 // chain guarantees that an event is re-recorded (batch b + depth) only after its consumer's wait for batch b has been made.
 // Everything that looks at the streams from outside (join, fork, reset, update_weights, destroy) first drains the posted batches
 // (sage_pipe_flush).  Needs four distinct role streams; not available inside a stream capture.
+//
+// Express lane (round 4).  A hand-off between two role streams is a record + wait packet pair, ~11 us from the producer's end to the
+// consumer's start (rocprofv3 trace).  In steady state the other streams' kernels run in those gaps; a batch submitted to
+// an IDLE pipeline pays all four of them with the chip empty: its output arrives after ~141 us where the five kernels need 86 back to back,
+// and the batches behind it inherit the delay.  So a batch that finds every earlier batch gone (the last batch's layer-2 event has
+// completed -- one hipEventQuery) is enqueued whole on stream L, like sage_forward2; the next batch starts on the role streams at once,
+// beside it.  Same kernels, same workspace, same arguments: bit-identical.  Not while capturing (an event query is not capturable);
+// needs four distinct role streams; SAGE_PIPE_EXPRESS=0 turns it off (A/B).
 #include <sched.h>
 #include <stdlib.h>
 
@@ -59,6 +67,7 @@ struct pipe_desc {                                      // one posted batch
     int64_t ldo;
     int slot;
     bool fresh;
+    bool express;                                       // an IDLE pipeline's batch: all five launches on stream L, no hand-off (see submit_one)
     void* gev[2];
 };
 }  // namespace
@@ -73,6 +82,7 @@ struct sage_pipe {
     hipEvent_t ev[4][SAGE_PIPE_MAX_DEPTH];              // [role][slot]: role's work on the slot's batch is enqueued
     hipEvent_t ev_fork;
     uint64_t submitted;
+    int64_t express_count;                              // batches that took the express lane (submitting thread only)
     // host enqueue threads
     int device;
     bool threaded;
@@ -169,6 +179,7 @@ extern "C" int sage_pipe_create(const sage_model_t* m, int32_t batch, int32_t de
     p->depth = depth;
     p->ws_bytes = workspace_bytes;
     p->submitted = 0;
+    p->express_count = 0;
     p->threaded = false;
     p->window = 0;
     p->device = 0;
@@ -230,6 +241,16 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
     const sage_model_t* m = &p->model;
     const int slot = d.slot;
     void* ws = p->ws[slot];
+    if (d.express) {
+        // the pipeline was idle at submit: no release to wait for, nothing to hand over; roles S, G, D have no calls to make
+        if (r != RL) return SAGE_OK;
+        const sage_ext_launch_t x{d.gev[0], d.gev[1]};
+        if (d.gev[0] && d.gev[1]) sage_ext_launch = &x;
+        const int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_ALL, p->st[RL]);
+        sage_ext_launch = nullptr;
+        if (rc) return rc;
+        return record(p, RL, slot, true);
+    }
     switch (r) {
     case RS:
         // S: outer + inner sample.  Needs the slot's previous batch to have left layer 2 (its last block zeroes the counters).
@@ -435,6 +456,21 @@ extern "C" int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window)
     return SAGE_OK;
 }
 
+// Every batch submitted so far has left layer 2 (and with it the GPU: L is a batch's last stage, stream L runs them in order).
+static bool express_on() {
+    static const bool on = [] { const char* v = getenv("SAGE_PIPE_EXPRESS"); return !(v && *v == '0'); }();
+    return on;
+}
+static bool pipe_idle(sage_pipe* p) {
+    if (!express_on()) return false;
+    for (int r = 0; r < 4; ++r)
+        for (int q = 0; q < r; ++q)
+            if (p->st[q] == p->st[r]) return false;           // coinciding role streams skip records: nothing to ask
+    if (p->submitted == 0) return true;                       // a new / reset pipe: the caller has synchronised what came before
+    if (p->threaded && p->done[RL].load(std::memory_order_acquire) < p->submitted) return false;   // the last batch's record has not been made yet
+    return hipEventQuery(p->ev[RL][(p->submitted - 1) % (uint64_t)p->depth]) == hipSuccess;
+}
+
 // One batch through the four role streams.
 static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* out, int64_t ldo, bool fresh_slot,
                       void* const* gather_events = nullptr) {
@@ -442,16 +478,21 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     d.seeds = seeds; d.key = key; d.out = out; d.ldo = ldo;
     d.slot = (int)(p->submitted % (uint64_t)p->depth);
     d.fresh = fresh_slot;
+    d.express = false;
     d.gev[0] = gather_events ? gather_events[0] : nullptr;
     d.gev[1] = gather_events ? gather_events[1] : nullptr;
     const int slot = d.slot;
     if (p->threaded) {
         SAGE_REQUIRE(p->cap_id[slot] == 0, "pipe: this slot's last batch was submitted inside a stream capture: call sage_pipe_reset first");
         if (int rc = p->worker_rc.load()) { sage_set_error("pipe: a role thread failed earlier (sage_pipe_flush reports it)"); return rc; }
+        d.express = pipe_idle(p);
+        p->express_count += d.express ? 1 : 0;
         return post(p, d);
     }
     unsigned long long cap = 0;
     if (int rc = capture_id(p->st[RS], &cap)) return rc;
+    d.express = cap == 0 && p->cap_id[slot] == 0 && pipe_idle(p);
+    p->express_count += d.express ? 1 : 0;
     for (int r = 0; r < 4; ++r)
         if (int rc = role_enqueue(p, r, d, cap)) return rc;
     p->cap_id[slot] = 0;
@@ -473,6 +514,8 @@ static int submit_one(sage_pipe* p, const int32_t* seeds, uint64_t key, float* o
     ++p->submitted;
     return SAGE_OK;
 }
+
+extern "C" int64_t sage_pipe_express_count(const sage_pipe_t* p) { return p ? p->express_count : -1; }
 
 // Forget every submit: the next `depth` submits find their workspaces free.  The caller has synchronised (or joined) everything
 // submitted before -- e.g. after a stream capture ended, before eager submission resumes on the same pipe.

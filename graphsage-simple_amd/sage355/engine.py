@@ -562,6 +562,10 @@ class RolePipeline:
         self.threads, self._window = False, int(window)
         if threads:
             self.set_threads(True, window)
+        # the workspaces were zeroed and initialised, the slice-major table copy and the weight planes written, on the CURRENT stream; the
+        # role streams are non-blocking streams of their own and would otherwise start the first batches beside that work (a sampler
+        # filling a frontier table that a memset is still wiping leaves stale keys behind for good)
+        self.fork()
 
     def set_threads(self, on, window=None):
         """Start (or drain and stop) the four host enqueue threads.  `window` > 0: role S enqueues batch b only once batch
@@ -622,6 +626,11 @@ class RolePipeline:
     def distinct_streams(self):
         """The pipe's distinct role streams, in first-use order of `roles` (pass them to another pipe's `streams=`)."""
         return list(self._streams.values())
+
+    @property
+    def express_count(self):
+        """Batches of this pipe that found it idle and were enqueued whole on stream L (csrc/sage_pipe.hip, "express lane")."""
+        return int(native.lib().sage_pipe_express_count(self._h))
 
     def fork(self, stream=None):
         """Every role stream waits for `stream` (default: the current one): inputs written there are ready."""

@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 ACT_RELU, ACT_SIGMOID, ACT_NONE = 0, 1, 2
 TAG_INNER, TAG_OUTER, TAG_INNER_SELF = 1, 2, 3
 MAX_FANOUT = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 EINVAL, EUNSUPPORTED, ELAUNCH, ENOSPACE = -1, -2, -3, -4      # include/sage355.h
 
 # every symbol include/sage355.h declares (tests check the library exports each one)
@@ -31,6 +31,7 @@ SYMBOLS = [
     "sage_prepared_weight_bytes", "sage_prepare_weights",
     "sage_pipe_create", "sage_pipe_destroy", "sage_pipe_update_weights", "sage_pipe_submit", "sage_pipe_submit_profiled", "sage_pipe_submit_many",
     "sage_pipe_join", "sage_pipe_fork", "sage_pipe_reset", "sage_pipe_set_threads", "sage_pipe_flush",
+    "sage_pipe_express_count",
 ]
 PIPE_MAX_DEPTH = 8
 
@@ -139,10 +140,13 @@ def lib():
     L.sage_pipe_reset.argtypes = [P]
     L.sage_pipe_set_threads.argtypes = [P, I32, I32]
     L.sage_pipe_flush.argtypes = [P]
+    L.sage_pipe_express_count.argtypes = [P]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name == "sage_prepared_weight_bytes" or name.endswith("_workspace_bytes"):
             fn.restype = c_size_t
+        elif name == "sage_pipe_express_count":
+            fn.restype = c_int64
         elif name not in ("sage_last_error", "sage_build_arch"):
             fn.restype = c_int32
     _lib = L

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SAGE_ABI_VERSION 5
+#define SAGE_ABI_VERSION 6
 
 #define SAGE_OK            0
 #define SAGE_EINVAL       -1   /* bad argument (NULL, size, alignment, range) */
@@ -430,6 +430,12 @@ int sage_pipe_reset(sage_pipe_t* p);
 int sage_pipe_set_threads(sage_pipe_t* p, int32_t on, int32_t window);
 /* Every posted batch has been enqueued on the role streams (not: has run).  Returns the first error a role thread met. */
 int sage_pipe_flush(sage_pipe_t* p);
+/* Express lane (ABI 6).  A batch submitted to an IDLE pipe -- every earlier batch has left layer 2, found with one hipEventQuery -- is
+ * enqueued whole on stream L, like sage_forward2, instead of being handed from stream to stream: four record + wait pairs of ~11 us
+ * each on an otherwise empty GPU (141 -> ~90 us to the first output of a region; the batches behind it start on the role streams at
+ * once).  Same kernels and workspace, bit-identical results; never inside a stream capture; needs four distinct role streams;
+ * SAGE_PIPE_EXPRESS=0 (environment, read once) turns it off.  Returns how many batches of this pipe took it so far (-1: NULL pipe). */
+int64_t sage_pipe_express_count(const sage_pipe_t* p);
 
 /* (ABI 5: sage_set_option is gone with the only option it carried -- the producer / consumer contraction kernel of round 3 was measured
  * slower inside the pipeline and deleted in round 4.) */

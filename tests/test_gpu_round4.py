@@ -110,3 +110,44 @@ def test_slice_major_copy_is_refreshed_in_place_under_a_live_pipe():
     assert e0._table_sliced.data_ptr() == ptr
     pipe.submit(seeds, 5, out[1]); pipe.synchronize()
     assert torch.equal(out[1], before)
+
+
+@pytest.mark.parametrize("threads", [False, True])
+def test_an_idle_pipes_batch_takes_the_express_lane_and_changes_no_bit(threads):
+    """Round 4: a batch submitted to an IDLE RolePipeline is enqueued whole on stream L (no stream-to-stream hand-offs on an empty GPU);
+    batches that find earlier ones in flight go through the role streams.  Both are the single forward's kernels on the same workspace
+    layout: every output equals TwoHopEngine.forward on the same (seeds, key) bit for bit, whichever lane it took."""
+    graph, table, w1, w2 = _rmat_problem(scale=14, edges=300_000)
+    rowptr, col = graph.to(DEV)
+    b, k1, k2, n = 2048, 15, 25, 12
+    cand = np.nonzero(graph.degrees() > 0)[0]
+    rs = np.random.default_rng(11)
+    seeds = torch.from_numpy(np.stack([rs.choice(cand, b, replace=False) for _ in range(n)]).astype(np.int32)).to(DEV)
+    keys = [1000 + i for i in range(n)]
+    args = (rowptr, col, table.to(DEV), w1.to(DEV), w2.to(DEV), k1, k2)
+    single = TwoHopEngine(*args, max_batch=b)
+    want = torch.stack([single.forward(seeds[i], seed=keys[i]).clone() for i in range(n)])
+    pipe = RolePipeline(*args, batch=b, depth=4, threads=threads)
+    assert pipe.express_count == 0
+    # (a) one batch at a time, the pipe drained in between: every batch finds it idle
+    out = torch.zeros(n, b, w2.shape[0], device=DEV)
+    for i in range(n):
+        pipe.submit(seeds[i], keys[i], out[i])
+        pipe.synchronize()
+    assert pipe.express_count == n
+    assert torch.equal(out, want)
+    # (b) all at once: the first finds the pipe idle, the ones behind it (submitted within microseconds) find it busy
+    out.zero_()
+    pipe.submit_many(seeds, keys, out)
+    pipe.synchronize()
+    took = pipe.express_count - n
+    assert 1 <= took < n, took
+    assert torch.equal(out, want)
+    # (c) and again after the drain, interleaved with single submits: whatever mix of lanes, the same bits
+    out.zero_()
+    for i in range(n):
+        pipe.submit(seeds[i], keys[i], out[i])
+        if i % 5 == 4:
+            pipe.synchronize()
+    pipe.synchronize()
+    assert torch.equal(out, want)
