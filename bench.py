@@ -109,7 +109,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsing N > 1 on a 1-GPU box)")
-    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (more than two ranks: the configs[3] "
+                                                                  "variant is off unless --scale-variant on: 45 GB per rank)")
     args = ap.parse_args()
     given = {a.split("=")[0].lstrip("-").replace("-", "_") for a in sys.argv[1:] if a.startswith("--")}
     args.exec_given = "exec" in given or "SAGE_EXEC" in os.environ
@@ -210,15 +211,28 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.share_device:
         local_rank = 0
+        if args.scale_variant == "auto" and world > 2:
+            # rehearsal on ONE device: configs[3] needs ~45 GB per rank (8.6 GB table, its degree-ordered copy and slice-major copy, twice:
+            # gate engine + pipeline) plus the sort temporaries of the relabelling; four ranks of it oversubscribe the 288 GB and the
+            # driver starts evicting whole processes -- a four-rank rehearsal sat in torch.sort for minutes (experiments/r04/call34.sh)
+            args.scale_variant = "off"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # SAGE_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, barriers, MAX all-reduce) with ONE rank -- the only way to run the
+    # RCCL calls of this file on a one-GPU box (tests/test_gpu_round4.py); two ranks on one device are refused by RCCL
+    if world > 1 or os.environ.get("SAGE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # RCCL; only barriers + one MAX all-reduce of the time
         else:
+            # one node, rendezvous on 127.0.0.1: keep gloo's pairs on the loopback interface too (the container's hostname may not resolve:
+            # a four-rank rehearsal once sat in gloo's full-mesh connect for seven minutes)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group(args.dist_backend)
 
     from sage355 import native
@@ -307,12 +321,32 @@ def host_plan(args, world):
             "role_threads": bool(threads)}
 
 
+_PROGRESS = {"fh": None, "t0": time.perf_counter()}
+
+
+def mark(rank, msg):
+    """SAGE_BENCH_PROGRESS=<dir>: every rank appends `seconds message` lines to <dir>/rank<r>.log (where a silent multi-rank run stands;
+    SAGE_BENCH_STACKS_AFTER=<seconds> adds a dump of every thread's Python stack there, once, if the run is still going by then)."""
+    d = os.environ.get("SAGE_BENCH_PROGRESS")
+    if not d:
+        return
+    if _PROGRESS["fh"] is None:
+        os.makedirs(d, exist_ok=True)
+        _PROGRESS["fh"] = open(os.path.join(d, f"rank{rank}.log"), "a", buffering=1)
+        after = float(os.environ.get("SAGE_BENCH_STACKS_AFTER", "0") or 0)
+        if after > 0:
+            import faulthandler
+            faulthandler.dump_traceback_later(after, exit=False, file=_PROGRESS["fh"])
+    _PROGRESS["fh"].write(f"{time.perf_counter() - _PROGRESS['t0']:8.2f} {msg}\n")
+
+
 def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_cpu):
     """One workload (args.config and the sizes its preset filled in) through the parity gate, the timed region, the timed-path check and
     the kernel / byte accounting.  Every rank runs it; rank 0 returns the dict the JSON line is made of, the others None."""
     t_setup = time.perf_counter()
     from sage355.engine import RolePipeline, TwoHopEngine
     from sage355.graph import rmat_graph
+    mark(rank, f"workload config {args.config}: start")
 
     # ---- synthetic inputs (SURVEY.md 8d): rank 0 generates, the others load its cache ----
     def make_graph():
@@ -335,6 +369,7 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
         dist.barrier()
     if rank != 0:
         graph = make_graph()
+    mark(rank, "graph ready")
     n = graph.num_nodes
     concat = args.mode == "concat"
     mult = 2 if concat else 1
@@ -361,6 +396,7 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
     relabel = "degree" if (args.engine_layout == "degree" and args.config != 2 and args.node_order != "degree") else None
     ekw = dict(concat=concat, agg_self_loop=args.self_loop, fused=not args.unfused, relabel=relabel)
     base = TwoHopEngine(rowptr, col, table, w1, w2, k1, k2, max_batch=b, **ekw)
+    mark(rank, "engine built")
     base_split = base.layout.layer1_split
     nstreams = max(1, args.streams)
 
@@ -387,6 +423,7 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
         if not parity_err <= 1e-5:
             raise SystemExit(f"parity gate failed: max |gpu-oracle|/rowmax = {parity_err:.3e}")
 
+    mark(rank, "parity gate done")
     # ---- execution modes of the timed region ----
     #  pipe   (default): RolePipeline -- stages S / G / D / L on role streams, `depth` batches in flight, one host call per batch
     #  replay          : hipGraph replay from a device batch queue, `streams` independent forwards in flight (round 1's mode)
@@ -485,9 +522,11 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
         if pipe is None and exec_mode == "replay":
             for e_ in engines:                    # the preheat used engine 0 directly: queue cursors are untouched, nothing to rewind
                 pass
+    mark(rank, "preheat done")
     # ---- warm-up, then the timed region: exactly K steps between two barrier+synchronize fences ----
     run(range(args.warmup))
     fence(pipe)
+    mark(rank, "warm-up done, opening fence passed")
     t0 = time.perf_counter()
     run(range(args.warmup, total_steps))
     host_submit_ms = (time.perf_counter() - t0) / args.steps * 1e3       # the submitting thread, per step
@@ -504,6 +543,7 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
         elapsed, own_done = float(t[0].item()), float(t[1].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * b * args.steps / elapsed
+    mark(rank, f"timed region done: {ms_per_step * 1e3:.1f} us per step")
 
     # ---- the timed path's own output, checked AFTER the clock stopped: what the timed execution mode left for the gate batch
     #      (the last timed step) against the oracle-gated single forward of the same (seeds, key), bit for bit ----
@@ -533,6 +573,7 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
                 + (" + self-loop (GCN-variant) aggregator [intended semantics of aggregators.py:50-51; the reference line raises TypeError, so this variant is parity-unpinned]" if args.self_loop else "")
                 + f" H={h1}/{h2}, fanout {k1}/{k2}, batch {b} seeds per GPU")
 
+    mark(rank, "timed-path check done")
     # ---- dominant kernel (layer-1 gather) duration, measured live with HIP events on the kernel's own stream:
     #      (a) IN SITU: the same K steps again in the same execution mode (the pipeline running, events around the gather on
     #          stream G) -- what the timed region's kernel launches took, overlap stretch included;
@@ -754,6 +795,7 @@ def run_workload(args, rank, world, dev, dist, fence, host, side_variants, with_
         was_pipe = pipe is not None
 
     result = None
+    mark(rank, "kernel accounting / variants done")
     # ---- CPU side by side: the reference-faithful restatement on this box's host cores ----
     cpu_baseline = None
     if rank == 0 and world == 1 and with_cpu:

@@ -151,3 +151,22 @@ def test_an_idle_pipes_batch_takes_the_express_lane_and_changes_no_bit(threads):
             pipe.synchronize()
     pipe.synchronize()
     assert torch.equal(out, want)
+
+
+def test_bench_rccl_calls_run_with_one_rank():
+    """The N > 1 code path of bench.py -- init_process_group("nccl", device_id), the fences' barriers, the MAX all-reduce of the elapsed
+    times on a DEVICE tensor, destroy -- has never met hardware with two GPUs (this pool hands out one).  With SAGE_BENCH_FORCE_DIST=1 a
+    single rank takes that path through RCCL: the calls themselves are exercised, and the line carries config.closing_fence."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAGE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--dist-backend", "nccl", "--steps", "20", "--warmup", "5",
+                        "--cpu-seconds", "0", "--preheat-seconds", "0.05", "--no-variant", "--scale-variant", "off"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cf = line["config"]["closing_fence"]
+    assert line["n_gpus"] == 1 and cf is not None and cf["barrier_us_in_timed_region"] >= 0
+    assert 0 < cf["slowest_rank_done_ms_per_step"] <= line["ms_per_step"] + 1e-5
+    assert line["timed_path_check"]["bit_identical_to_oracle_gated_forward"] is True
