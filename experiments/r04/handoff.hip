@@ -3,8 +3,10 @@
 //   0 one stream (baseline)            1 hipEvent, DisableTiming | DisableSystemFence (the product's)     2 hipEvent, DisableTiming only
 //   3 hipStreamWriteValue32 / hipStreamWaitValue32 on device memory        4 the same on signal memory (hipMallocSignalMemory)
 //   5 one-thread signal / gate kernels on a device counter (round 4's "flags")
+//   6 the kernel's OWN completion signal as the event (hipExtLaunchKernelGGL stopEvent) + hipStreamWaitEvent: no record packet      7 the same, events with the system fence
 // build: hipcc -O3 --offload-arch=gfx950 handoff.hip -o handoff        run: ./handoff [kernel_us] [n]
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -45,11 +47,12 @@ int main(int argc, char** argv) {
         CK(hipEventCreateWithFlags(&ev[0][i], hipEventDisableTiming | hipEventDisableSystemFence));
         CK(hipEventCreateWithFlags(&ev[1][i], hipEventDisableTiming));
     }
-    const char* names[6] = {"one stream", "hipEvent (no timing, no system fence)", "hipEvent (no timing)", "hipStreamWrite/WaitValue32, device memory",
-                            "hipStreamWrite/WaitValue32, signal memory", "signal / gate kernels"};
+    const char* names[8] = {"one stream", "hipEvent (no timing, no system fence)", "hipEvent (no timing)", "hipStreamWrite/WaitValue32, device memory",
+                            "hipStreamWrite/WaitValue32, signal memory", "signal / gate kernels",
+                            "stopEvent of the launch + wait (no fence)", "stopEvent of the launch + wait"};
     double base = 0;
     unsigned long long seq = 0; uint32_t vseq = 0;
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
         if ((mode == 3 || mode == 4) && !can) { printf("%-45s unsupported\n", names[mode]); continue; }
         if (mode == 4 && !val_sig) { printf("%-45s no signal memory\n", names[mode]); continue; }
         double best = 1e30;
@@ -60,11 +63,13 @@ int main(int argc, char** argv) {
                 const int me = mode == 0 ? 0 : (i & 1), other = me ^ 1;
                 if (i > 0) {                                  // wait for kernel i-1 (on the other stream)
                     if (mode == 1 || mode == 2) CK(hipStreamWaitEvent(s[me], ev[mode - 1][other], 0));
+                    else if (mode == 6 || mode == 7) CK(hipStreamWaitEvent(s[me], ev[mode - 6][other], 0));
                     else if (mode == 3) CK(hipStreamWaitValue32(s[me], val_dev, vseq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                     else if (mode == 4) CK(hipStreamWaitValue32(s[me], val_sig, vseq, hipStreamWaitValueGte, 0xFFFFFFFFu));
                     else if (mode == 5) hipLaunchKernelGGL(gate, dim3(1), dim3(1), 0, s[me], flag, seq);
                 }
-                hipLaunchKernelGGL(busy, dim3(blocks), dim3(256), 0, s[me], ticks, sink);
+                if (mode == 6 || mode == 7) hipExtLaunchKernelGGL(busy, dim3(blocks), dim3(256), 0, s[me], nullptr, ev[mode - 6][me], 0u, ticks, sink);
+                else hipLaunchKernelGGL(busy, dim3(blocks), dim3(256), 0, s[me], ticks, sink);
                 if (mode == 1 || mode == 2) CK(hipEventRecord(ev[mode - 1][me], s[me]));
                 else if (mode == 3) CK(hipStreamWriteValue32(s[me], val_dev, ++vseq, 0));
                 else if (mode == 4) CK(hipStreamWriteValue32(s[me], val_sig, ++vseq, 0));

@@ -9,6 +9,7 @@
 //   * one barrier per tile (the double buffer makes the second one unnecessary);
 //   * operands as in sage_fused.hip: lane (i = l&31, h = l>>5) supplies A[i][8q+4h+t] / W[n0+i][8q+4h+t]
 //     to MFMA 4q+t; LDS rows padded by one ds_read_b128 width.
+#include <atomic>
 #include "sage_internal.h"
 
 namespace {
@@ -157,14 +158,14 @@ template <int KP, bool CONCAT>
 int launch(const DenseArgs& a, hipStream_t st) {
     constexpr bool KSPLIT = CONCAT && KP == 256;
     constexpr size_t lds = ((size_t)2 * (CONCAT ? 2 : 1) * 32 * (KP + 4) + (KSPLIT ? 4 * 16 * 64 : 0)) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};           // role threads (and the express lane's thread) may launch the same kernel concurrently
+    if (!configured.load(std::memory_order_acquire)) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_layer_kernel<KP, CONCAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess) {
             sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
         }
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     // one persistent block per CU (24.9 us) beat two (26.3 us) on the config-3 contraction: the prefetch only pays
     // when a block owns >= 2 tiles, and one block per CU leaves wave slots for another batch's kernels
@@ -172,7 +173,7 @@ int launch(const DenseArgs& a, hipStream_t st) {
 #define SAGE_DENSE_PER_CU 1
 #endif
     const int grid = min(sage_cdiv(a.n, 32), SAGE_DENSE_PER_CU * kNumCU);
-    hipLaunchKernelGGL((dense_layer_kernel<KP, CONCAT>), dim3(grid), dim3(KSPLIT ? 512 : 256), lds, st, a);
+    SAGE_LAUNCH_TAIL((dense_layer_kernel<KP, CONCAT>), dim3(grid), dim3(KSPLIT ? 512 : 256), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_layer_kernel");
     return SAGE_OK;
 }
@@ -594,21 +595,21 @@ int launch_bf16x3(const DenseArgs& a, hipStream_t st) {
         if (a.wsplit) return launch_bf16x3<KP, CONCAT, MP, true>(a, st);
     constexpr int KPASS = (CONCAT && KP < 256) ? 2 * KP : KP;
     constexpr size_t lds = (size_t)2 * 3 * 32 * (KPASS + 8) * 2 + (size_t)2 * 32 * (128 + 4) * sizeof(float) + 384;
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};           // role threads (and the express lane's thread) may launch the same kernel concurrently
+    if (!configured.load(std::memory_order_acquire)) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dense_bf16x3_kernel<KP, CONCAT, MP, PREP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess) {
             sage_set_error("layer_dense: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
         }
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     // Persistent blocks on 3/4 of the CUs: alone that costs 1-2 us (4 tile rounds instead of 3), with a second batch in
     // flight it is worth 3 us per forward -- a block holds 344 of a SIMD's 512 VGPRs and 117 KB of LDS for its whole life,
     // and the other batch's latency-bound kernels get the remaining CUs to themselves (same-box A/B: 184-224 blocks
     // 81.3-81.9 us, 256 blocks 84.2, 160 blocks 83.1).
     const int grid = min(sage_cdiv(a.n, 32), sage_tunables().dense_blocks);
-    hipLaunchKernelGGL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP>), dim3(grid), dim3(512), lds, st, a);
+    SAGE_LAUNCH_TAIL((dense_bf16x3_kernel<KP, CONCAT, MP, PREP>), dim3(grid), dim3(512), lds, st, a);
     SAGE_CHECK_LAUNCH("dense_bf16x3_kernel");
     return SAGE_OK;
 }

@@ -84,7 +84,7 @@ namespace {
 
 int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
                   uint64_t seed, float* out, int64_t ldo, sage_stream_t stream, void* const* ev, int stages = SAGE_STAGE_ALL,
-                  int cursor_off = 0, bool key_in_ws = false) {
+                  int cursor_off = 0, bool key_in_ws = false, void* tail_event = nullptr) {
     if (int rc = check_model(m)) return rc;
     SAGE_REQUIRE(m->rowptr1 && m->col1 && m->rowptr2 && m->col2 && m->table && m->w1 && m->w2, "forward2: NULL model array");
     const bool queued = m->queue != nullptr;
@@ -101,6 +101,21 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
         return SAGE_ENOSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    // tail_event (sage_pipe.hip): to be recorded behind the LAST launch of `stages` -- as that launch's own completion signal where its
+    // launcher knows SAGE_LAUNCH_TAIL (arm() right before the stage's final launcher call), by hipEventRecord otherwise (settle())
+    int last_stage = 0;
+    for (int bit = SAGE_STAGE_LAYER2; bit >= 1; bit >>= 1)
+        if (tail_event && (stages & bit)) { last_stage = bit; break; }
+    struct TailGuard { ~TailGuard() { sage_tail_event = nullptr; } } tail_guard;      // an error return must not leave it armed on this thread
+    bool armed = false;
+    auto arm = [&](int stage) { if (stage == last_stage) { sage_tail_event = tail_event; armed = true; } };
+    auto settle = [&](int stage) -> int {
+        if (stage != last_stage) return SAGE_OK;
+        if (armed && !sage_tail_event) return SAGE_OK;                                // the stage's last launch carried it
+        sage_tail_event = nullptr;                                                    // nothing launched, or by a launcher that does not know it
+        if (hipEventRecord((hipEvent_t)tail_event, st) != hipSuccess) { sage_set_error("forward2: hipEventRecord failed"); return SAGE_ELAUNCH; }
+        return SAGE_OK;
+    };
     char* ws = (char*)workspace;
     int32_t* counters = (int32_t*)(ws + L.counters);
     int32_t* s1_count = counters + 0;      // frontier rows claimed so far (zero based; rows start at first_row)
@@ -156,14 +171,18 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
         SAGE_EV(1);
         SAGE_EV(2);
         SAGE_EV(3);
+        if (last_stage == SAGE_STAGE_SAMPLE_INNER || last_stage == SAGE_STAGE_SAMPLE_OUTER)
+            if (int rc = settle(last_stage)) return rc;
     }
     if (!sfused && (stages & SAGE_STAGE_SAMPLE_OUTER)) {
     // 1. outer hop: seeds -> nbr2, hash insert -> frontier rows [first_row, ...)
     SAGE_EV(0);
+    arm(SAGE_STAGE_SAMPLE_OUTER);
     if (int rc = sage_launch_sample(m->rowptr2, m->col2, m->num_nodes, seeds, batch, nullptr, m->k2, seed, SAGE_TAG_OUTER, 0, SAGE_TAG_OUTER, nbr2,
                                     cnt2, (m->nan_empty && self_loop) ? any2 : nullptr, &fr, self_loop, slot2, self_slot2, qm, 1, m->concat ? s1_nodes : nullptr, 0, first_row,
                                     nullptr, cursor_off, key_slot, m->seed_map, st))
         return rc;
+    if (int rc = settle(SAGE_STAGE_SAMPLE_OUTER)) return rc;
     SAGE_EV(1);
     }
     if (!sfused && (stages & SAGE_STAGE_SAMPLE_INNER)) {
@@ -173,10 +192,12 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     //    100 us, its per-row dependent chain growing from 2 to 5 round trips.)
     const sage_resolve_t resolve{slot2, row2, batch * m->k2, self_loop ? self_slot2 : nullptr, self_row2, batch, fr.rows, fr.keys};
     SAGE_EV(2);
+    arm(SAGE_STAGE_SAMPLE_INNER);
     if (int rc = sage_launch_sample(m->rowptr1, m->col1, m->num_nodes, s1_nodes, L.max_s1, s1_count, m->k1, seed, SAGE_TAG_INNER, first_row,
                                     SAGE_TAG_INNER_SELF, nbr1, cnt1, m->nan_empty ? any1 : nullptr, nullptr, 0, nullptr, nullptr, qm, 0, nullptr, first_row, 0,
                                     &resolve, cursor_off, key_slot, nullptr, st))
         return rc;
+    if (int rc = settle(SAGE_STAGE_SAMPLE_INNER)) return rc;
     SAGE_EV(3);
     }
     // serving on a pre-transformed table (sage_model_t.w1_is_identity): the split layer's gather applies act1 and writes h1; no contraction
@@ -189,6 +210,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     const bool ext_g = ev && ev[4] && ev[5] && (gather_only1 || split1) && sage_ext_launch == nullptr;
     if (ext_g) sage_ext_launch = &gx; else SAGE_EV(4);
     struct ClearHook { bool on; ~ClearHook() { if (on) sage_ext_launch = nullptr; } } clear_hook{ext_g};
+    arm(SAGE_STAGE_GATHER1);               // (a launch that carries the measurement hook's events leaves it armed: settle() records)
     if (gather_only1) {
         const int sw = m->table_slice_floats ? m->table_slice_floats : 64;
         const bool sm = m->table_sliced != nullptr && (sw == 32 || sw == 64 || sw == 128) && m->d0 % sw == 0 && sage_aligned(m->table_sliced, 16);
@@ -205,6 +227,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                              sm ? m->num_nodes * (int64_t)sw : 0))
             return rc;
     }
+    if (int rc = settle(SAGE_STAGE_GATHER1)) return rc;
     if (!ext_g) SAGE_EV(5);
     }
     // ... and its contraction (one launch with the gather unless the layer is split); then layer 2
@@ -213,10 +236,12 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     if (gather_only1) {
         // nothing: the gather wrote h1
     } else if (split1) {
+        arm(SAGE_STAGE_CONTRACT1);
         if (int rc = sage_launch_layer_dense(agg1, m->d0, m->d0, L.max_s1, s1_count, m->concat, m->table, m->table_ld, m->num_nodes,
                                              s1_nodes, nullptr, nullptr, m->w1, ldw1, m->h1, m->act1, h1, m->h1, first_row, no_fin, m->w1_prepared, st))
             return rc;
     } else if (fuse1) {
+        arm(SAGE_STAGE_CONTRACT1);
         if (int rc = sage_launch_layer_fused(m->table, m->num_nodes, m->table_ld, m->d0, nbr1, cnt1, m->k1, L.max_s1, s1_count, nullptr,
                                              self_loop ? s1_nodes : nullptr, nan1, m->concat, s1_nodes, m->w1, ldw1, m->h1, m->act1,
                                              h1, m->h1, first_row, no_fin, st))
@@ -229,6 +254,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                             m->h1, m->act1, L.max_s1, s1_count, h1, m->h1, first_row, no_fin, st))
             return rc;
     }
+    if (int rc = settle(SAGE_STAGE_CONTRACT1)) return rc;
     SAGE_EV(7);
     }
     if (stages & SAGE_STAGE_LAYER2) {
@@ -237,11 +263,13 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
     if (fuse2 && sfused) {
         // slots in, rows resolved (and left in row2 / self_row2), keys wiped: the duties the inner-hop launch had
         const sage_slot_resolve_t rs{fr.keys, row2, self_loop ? self_row2 : nullptr};
+        arm(SAGE_STAGE_LAYER2);
         if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, slot2, cnt2, m->k2, batch, nullptr, fr.rows,
                                              self_loop ? self_slot2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
                                              out, ldo, 0, fin, st, &rs))
             return rc;
     } else if (fuse2) {
+        arm(SAGE_STAGE_LAYER2);
         if (int rc = sage_launch_layer_fused(h1, L.max_s1, m->h1, m->h1, row2, cnt2, m->k2, batch, nullptr, nullptr,
                                              self_loop ? self_row2 : nullptr, nan2, m->concat, nullptr, m->w2, ldw2, m->h2, m->act2,
                                              out, ldo, 0, fin, st))
@@ -254,6 +282,7 @@ int forward2_impl(const sage_model_t* m, void* workspace, size_t workspace_bytes
                                             batch, nullptr, out, ldo, 0, fin, st))
             return rc;
     }
+    if (int rc = settle(SAGE_STAGE_LAYER2)) return rc;
     SAGE_EV(9);
     }
     return SAGE_OK;
@@ -267,8 +296,8 @@ extern "C" int sage_forward2(const sage_model_t* m, void* workspace, size_t work
 
 // A subset of the forward's launches with the seeds and the sampler key taken from the call (sage_pipe.hip: one call per role stream)
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
-                                uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream) {
-    return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, (sage_stream_t)stream, nullptr, stages, 0, false);
+                                uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream, void* tail_event) {
+    return forward2_impl(m, workspace, workspace_bytes, seeds, batch, seed, out, ldo, (sage_stream_t)stream, nullptr, stages, 0, false, tail_event);
 }
 
 extern "C" int sage_forward2_profiled(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds,

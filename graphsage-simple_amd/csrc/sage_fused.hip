@@ -20,6 +20,7 @@
 // HBM-bound: the gather moves ~14 KiB per destination row against 65 kFLOP of MFMA work, so the
 // matrix pipe is idle most of the time; two blocks per CU (LDS 66.5 KiB each at M=64, KP=256;
 // <= 256 VGPRs) let one block's MFMA phase hide under the other's gather.
+#include <atomic>
 #include "sage_internal.h"
 
 namespace {
@@ -452,9 +453,9 @@ int launch_tile16(const FusedArgs& a, hipStream_t st) {
     const int tiles = sage_cdiv(a.n, 16);
     const int grid = min(tiles, sage_tunables().tile16_grid);
     if (sage_tunables().tile16_waves == 8)
-        hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT, 8>), dim3(grid), dim3(512), 0, st, a);
+        SAGE_LAUNCH_TAIL((layer_tile16_kernel<KP, CONCAT, INFLIGHT, 8>), dim3(grid), dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL((layer_tile16_kernel<KP, CONCAT, INFLIGHT, 16>), dim3(grid), dim3(1024), 0, st, a);
+        SAGE_LAUNCH_TAIL((layer_tile16_kernel<KP, CONCAT, INFLIGHT, 16>), dim3(grid), dim3(1024), 0, st, a);
     SAGE_CHECK_LAUNCH("layer_tile16_kernel");
     return SAGE_OK;
 }
@@ -462,20 +463,20 @@ int launch_tile16(const FusedArgs& a, hipStream_t st) {
 template <int KP, int M, int WAVES, bool WREG, bool CONCAT, int INFLIGHT = 8>
 int launch(const FusedArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(CONCAT ? 2 : 1) * M * (KP + 4) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};           // role threads (and the express lane's thread) may launch the same kernel concurrently
+    if (!configured.load(std::memory_order_acquire)) {
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute((const void*)layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             sage_set_error("layer_forward: cannot reserve %zu bytes of LDS", lds);
             return SAGE_ELAUNCH;
         }
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int tiles = sage_cdiv(a.n, M);
     const int per_cu = WAVES >= 16 ? 2 : (WAVES == 8 ? 1 : (WREG ? 2 : 4));
     const int grid = min(tiles, per_cu * kNumCU);
-    hipLaunchKernelGGL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>), dim3(grid), dim3(WAVES * 64), lds, st, a);
+    SAGE_LAUNCH_TAIL((layer_fused_kernel<KP, M, WAVES, WREG, CONCAT, INFLIGHT>), dim3(grid), dim3(WAVES * 64), lds, st, a);
     SAGE_CHECK_LAUNCH("layer_fused_kernel");
     return SAGE_OK;
 }

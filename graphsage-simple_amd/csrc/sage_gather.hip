@@ -15,6 +15,7 @@
 // hipExtLaunchKernelGGL with these two TIMING events as the launch's own start / stop events, i.e. the interval is the kernel's
 // execution (what rocprofv3 reports) and not the distance between two marker packets around it in a busy queue.
 thread_local const sage_ext_launch_t* sage_ext_launch = nullptr;
+thread_local void* sage_tail_event = nullptr;
 
 namespace {
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gather_mean_rows_kernel(
         if (const sage_ext_launch_t* x_ = sage_ext_launch)                                                                           \
             hipExtLaunchKernelGGL((kernel), dim3(blocks), dim3(256), 0, st, (hipEvent_t)x_->start, (hipEvent_t)x_->stop, 0u, __VA_ARGS__); \
         else                                                                                                                         \
-            hipLaunchKernelGGL((kernel), dim3(blocks), dim3(256), 0, st, __VA_ARGS__);                                               \
+            SAGE_LAUNCH_TAIL((kernel), dim3(blocks), dim3(256), 0, st, __VA_ARGS__);                                                 \
     } while (0)
 
 template <int SL, typename... A>

@@ -65,6 +65,27 @@ int sage_launch_layer_dense(const float* agg, int64_t ld_agg, int32_t dim, int32
 struct sage_ext_launch_t { void* start; void* stop; };
 extern thread_local const sage_ext_launch_t* sage_ext_launch;
 
+// Tail event (round 4).  A stage's hand-off event can ride on the stage's LAST kernel as that dispatch's own completion signal
+// (hipExtLaunchKernel stopEvent) instead of being a packet of its own behind the kernel (hipEventRecord): one barrier packet less between
+// two kernels of a role stream (experiments/r04/handoff.hip: 7.3 against 8.5 us per hand-off; in the pipeline the record was one of the two
+// packets that separate consecutive kernels of a stream).  One-shot and thread-local: whoever is about to call the launcher of a stage's
+// last kernel sets it; the first launch made through SAGE_LAUNCH_TAIL consumes it; a launcher that does not know it leaves it set, and the
+// setter then records the event explicitly (sage_forward.hip).  Never while a stream is capturing.
+extern thread_local void* sage_tail_event;
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#define SAGE_LAUNCH_TAIL(kernel, grid, block, lds, st, ...)                                                               \
+    do {                                                                                                                  \
+        if (sage_tail_event) {                                                                                            \
+            hipEvent_t tail_ = (hipEvent_t)sage_tail_event;                                                               \
+            sage_tail_event = nullptr;                                                                                    \
+            hipExtLaunchKernelGGL((kernel), (grid), (block), (lds), (st), nullptr, tail_, 0u, __VA_ARGS__);               \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL((kernel), (grid), (block), (lds), (st), __VA_ARGS__);                                      \
+        }                                                                                                                 \
+    } while (0)
+#endif
+
 // The launches of one forward, by stage (sage_pipe.hip enqueues each stage on its role stream)
 #define SAGE_STAGE_SAMPLE_OUTER 1
 #define SAGE_STAGE_SAMPLE_INNER 2
@@ -73,7 +94,7 @@ extern thread_local const sage_ext_launch_t* sage_ext_launch;
 #define SAGE_STAGE_LAYER2       16
 #define SAGE_STAGE_ALL          31
 int sage_forward2_launch_stages(const sage_model_t* m, void* workspace, size_t workspace_bytes, const int32_t* seeds, int32_t batch,
-                                uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream);
+                                uint64_t seed, float* out, int64_t ldo, int32_t stages, hipStream_t stream, void* tail_event = nullptr);
 
 // Launch-shape tunables, read ONCE from the environment (A/B runs on one box without rebuilding; defaults are the
 // measured optima recorded in DESIGN.md).  Every value is clamped to a safe range.

@@ -241,15 +241,20 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
     const sage_model_t* m = &p->model;
     const int slot = d.slot;
     void* ws = p->ws[slot];
+    // the role's hand-off event rides on its stage's last kernel (sage_internal.h: tail event) instead of being recorded behind it -- not while
+    // capturing (hipExtLaunchKernel is not a capturable launch), and SAGE_PIPE_TAIL=0 keeps the separate record (A/B)
+    static const bool tail_on = [] { const char* v = getenv("SAGE_PIPE_TAIL"); return !(v && *v == '0'); }();
+    auto tail = [&](int role, bool needed) -> void* { return (tail_on && cap == 0 && needed) ? (void*)p->ev[role][slot] : nullptr; };
     if (d.express) {
         // the pipeline was idle at submit: no release to wait for, nothing to hand over; roles S, G, D have no calls to make
         if (r != RL) return SAGE_OK;
         const sage_ext_launch_t x{d.gev[0], d.gev[1]};
         if (d.gev[0] && d.gev[1]) sage_ext_launch = &x;
-        const int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_ALL, p->st[RL]);
+        const int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_ALL, p->st[RL],
+                                                   tail(RL, true));
         sage_ext_launch = nullptr;
         if (rc) return rc;
-        return record(p, RL, slot, true);
+        return tail(RL, true) ? SAGE_OK : record(p, RL, slot, true);
     }
     switch (r) {
     case RS:
@@ -274,8 +279,9 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
                            // only together with everything else ("events only"): the samplers fill and layer 2 wipes the frontier hash, and
                            // one without the other leaves a full table behind (an outer sampler probing it took 67 ms per batch)
         if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0,
-                                                 SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS]))
+                                                 SAGE_STAGE_SAMPLE_OUTER | SAGE_STAGE_SAMPLE_INNER, p->st[RS], tail(RS, p->st[RG] != p->st[RS])))
             return rc;
+        if (tail(RS, p->st[RG] != p->st[RS])) return SAGE_OK;
 #endif
         return record(p, RS, slot, p->st[RG] != p->st[RS]);
     case RG:
@@ -286,9 +292,11 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
             // profiled submit: the two caller-owned timing events become the gather launch's OWN start / stop events (sage_gather.hip)
             const sage_ext_launch_t x{d.gev[0], d.gev[1]};
             if (d.gev[0] && d.gev[1]) sage_ext_launch = &x;
-            const int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG]);
+            const int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_GATHER1, p->st[RG],
+                                                       tail(RG, p->st[RD] != p->st[RG]));
             sage_ext_launch = nullptr;
             if (rc) return rc;
+            if (tail(RG, p->st[RD] != p->st[RG])) return SAGE_OK;
         }
 #endif
         return record(p, RG, slot, p->st[RD] != p->st[RG]);
@@ -296,14 +304,20 @@ static int role_enqueue(sage_pipe* p, int r, const pipe_desc& d, unsigned long l
         // D: the contraction (or the whole fused layer 1)
         if (int rc = wait_on(p, RD, RG, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_D
-        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD])) return rc;
+        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, nullptr, 0, SAGE_STAGE_CONTRACT1, p->st[RD],
+                                                 tail(RD, p->st[RL] != p->st[RD])))
+            return rc;
+        if (tail(RD, p->st[RL] != p->st[RD])) return SAGE_OK;
 #endif
         return record(p, RD, slot, p->st[RL] != p->st[RD]);
     default:
         // L: layer 2; afterwards the workspace is clean again
         if (int rc = wait_on(p, RL, RD, slot, cap != 0)) return rc;
 #ifndef SAGE_PIPE_SKIP_L
-        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_LAYER2, p->st[RL])) return rc;
+        if (int rc = sage_forward2_launch_stages(m, ws, p->ws_bytes, d.seeds, p->batch, d.key, d.out, d.ldo, SAGE_STAGE_LAYER2, p->st[RL],
+                                                 tail(RL, p->st[RS] != p->st[RL])))
+            return rc;
+        if (tail(RL, p->st[RS] != p->st[RL])) return SAGE_OK;
 #endif
         return record(p, RL, slot, p->st[RS] != p->st[RL]);
     }

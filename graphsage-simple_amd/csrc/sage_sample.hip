@@ -99,7 +99,7 @@ int check_frontier(const sage_frontier_t* f, int64_t inserts) {
 
 template <int G, int THREADS, bool SAMPLE, bool FRONTIER, typename... A>
 void launch_one(int n, hipStream_t st, A... args) {
-    hipLaunchKernelGGL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(sage_cdiv(n, THREADS / G)), dim3(THREADS), 0, st, args...);
+    SAGE_LAUNCH_TAIL((sample_kernel<G, THREADS, SAMPLE, FRONTIER>), dim3(sage_cdiv(n, THREADS / G)), dim3(THREADS), 0, st, args...);
 }
 
 template <int T, bool SAMPLE, bool FRONTIER, typename... A>
