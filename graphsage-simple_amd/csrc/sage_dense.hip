@@ -196,12 +196,26 @@ int launch(const DenseArgs& a, hipStream_t st) {
 #define SAGE_MP_TG 1
 #endif
 #ifdef SAGE_DENSE_STAMPS     // diagnostic build (experiments/): where a persistent block's time goes; never in the product library
+// Stamps are 100 MHz real-time ticks (s_memrealtime: one clock for the whole device, so block starts on different XCDs compare).  Only the
+// launch selected with sage_debug_dense_select() is stamped (launch = blocks started so far / grid: launches of a stream never overlap),
+// so that a launch in the MIDDLE of a running pipeline can be looked at, not only the last one.
 __device__ unsigned long long g_dense_stamps[512 * 40];
+__device__ unsigned int g_dense_blocks;
+__device__ int g_dense_target = -1;                      // -1: every launch (the last one wins)
 extern "C" int sage_debug_dense_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dense_stamps), sizeof(g_dense_stamps)) == hipSuccess ? 0 : -1;
 }
-#define STAMP(i) do { if (threadIdx.x == 0 && (i) < 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_dense_stamps[blockIdx.x * 40 + (i)] = t_; } } while (0)
+extern "C" int sage_debug_dense_select(int launch) {
+    const unsigned int zero = 0;
+    static unsigned long long zeros[512 * 40];
+    return (hipMemcpyToSymbol(HIP_SYMBOL(g_dense_target), &launch, sizeof(int)) == hipSuccess &&
+            hipMemcpyToSymbol(HIP_SYMBOL(g_dense_blocks), &zero, sizeof(zero)) == hipSuccess &&
+            hipMemcpyToSymbol(HIP_SYMBOL(g_dense_stamps), zeros, sizeof(zeros)) == hipSuccess) ? 0 : -1;
+}
+#define STAMP_DECL __shared__ int stamp_on_; if (threadIdx.x == 0) { const unsigned int o_ = atomicAdd(&g_dense_blocks, 1u); stamp_on_ = (g_dense_target < 0 || (int)(o_ / gridDim.x) == g_dense_target) ? 1 : 0; }
+#define STAMP(i) do { if (threadIdx.x == 0 && (i) < 40 && stamp_on_) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_dense_stamps[blockIdx.x * 40 + (i)] = t_; } } while (0)
 #else
+#define STAMP_DECL
 #define STAMP(i) do { } while (0)
 #endif
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -292,6 +306,7 @@ __global__ __launch_bounds__(512) void dense_bf16x3_kernel(const DenseArgs a) {
                                                                  // [32 + 32 b + r]: row r of the tile staged in buffer b holds a huge value
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STAMP_DECL
     int nn = a.n;
     if (a.n_dev) nn = min(*a.n_dev + a.n_off, a.n);
     const int ntiles = (nn + M - 1) / M;
